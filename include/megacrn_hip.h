@@ -1,0 +1,159 @@
+/*
+ * megacrn_hip.h - C ABI of libmegacrn_hip.so (gfx950 / MI355X).
+ *
+ * The reference (deepkashiwa20/MegaCRN) has no native layer: its hot path is the
+ * ATen ops invoked by model/MegaCRN.py:7-194.  This library replaces exactly
+ * those ops with hand-written HIP kernels; each entry point below names the
+ * reference lines it stands in for.  The reference-side binding is the ctypes
+ * stub in INTEGRATION.md (and megacrn_amd/_lib.py).
+ *
+ * Conventions
+ *  - All tensor pointers are DEVICE pointers to contiguous fp32 row-major
+ *    arrays in the reference layout: x (B,T,N,C), state (B,N,H), support (N,N),
+ *    AGCN weights (2*cheb_k*C, O) with row index k_global*C + c
+ *    (model/MegaCRN.py:24-27).  int arguments named `teacher` are HOST arrays.
+ *  - `stream` is a hipStream_t (passed as void*).  Kernels are enqueued on it;
+ *    no entry point synchronises, allocates or frees device memory: all
+ *    scratch and saved activations live in the caller-provided workspace `ws`
+ *    of at least mcrn_*_workspace_bytes() bytes (256-byte aligned).
+ *  - A forward call leaves its saved activations in `ws`; the matching
+ *    backward call must receive the same `ws` untouched.
+ *  - Return value: 0 on success, otherwise a hipError_t (>0) or
+ *    MCRN_EINVAL (-1) for unsupported arguments; mcrn_last_error() returns a
+ *    static message.
+ *  - Supported: cheb_k in {2,3}; any B,N,H,input/output/ycov dims >= 1;
+ *    num_layers == 1 in the fused model entry points (multi-layer models are
+ *    composed from mcrn_cell_* by the host module).
+ */
+#ifndef MEGACRN_HIP_H
+#define MEGACRN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRN_EINVAL (-1)
+
+/* compute precision of the MFMA contractions */
+#define MCRN_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+
+typedef struct mcrn_dims {
+    int B;          /* batch */
+    int N;          /* num_nodes */
+    int T_in;       /* encoder sequence length */
+    int T_out;      /* horizon */
+    int input_dim;
+    int output_dim;
+    int ycov_dim;
+    int H;          /* rnn_units */
+    int mem_num;    /* M */
+    int mem_dim;    /* D */
+    int cheb_k;     /* 2 or 3 */
+    int precision;  /* MCRN_F32 */
+} mcrn_dims_t;
+
+/* parameter pointers, named after the reference state_dict keys (num_layers=1) */
+typedef struct mcrn_params {
+    const float *Memory, *Wq, *We1, *We2;                /* memory.*            MegaCRN.py:149-157 */
+    const float *enc_gate_w, *enc_gate_b;                /* encoder.dcrnn_cells.0.gate.{weights,bias} */
+    const float *enc_update_w, *enc_update_b;
+    const float *dec_gate_w, *dec_gate_b;                /* decoder.dcrnn_cells.0.* */
+    const float *dec_update_w, *dec_update_b;
+    const float *proj_w, *proj_b;                        /* proj.0.{weight,bias}  MegaCRN.py:144 */
+} mcrn_params_t;
+
+typedef struct mcrn_grads {
+    float *Memory, *Wq, *We1, *We2;
+    float *enc_gate_w, *enc_gate_b, *enc_update_w, *enc_update_b;
+    float *dec_gate_w, *dec_gate_b, *dec_update_w, *dec_update_b;
+    float *proj_w, *proj_b;
+} mcrn_grads_t;
+
+const char* mcrn_last_error(void);
+int mcrn_version(void);
+
+/* ---- whole model: MegaCRN.forward, model/MegaCRN.py:168-194, and its autograd backward ---- */
+size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d);
+
+/* x (B,T_in,N,input_dim), ycov (B,T_out,N,ycov_dim), labels (B,T_out,N,output_dim) or NULL.
+ * teacher[t] != 0  <=>  `go = labels[:, t]` after step t (the curriculum branch, :188-191);
+ * NULL means all zero.  Outputs: output (B,T_out,N,output_dim), h_att/query/pos/neg (B,N,mem_dim). */
+int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p,
+                       const float* x, const float* ycov, const float* labels, const int* teacher,
+                       void* ws, size_t ws_bytes,
+                       float* output, float* h_att, float* query, float* pos, float* neg,
+                       void* stream);
+
+/* Gradients of every parameter given d(output), and optionally d(h_att), d(query), d(pos), d(neg)
+ * (NULL = zero).  `grads` tensors are overwritten (not accumulated). */
+int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher,
+                        const float* d_output, const float* d_hatt, const float* d_query,
+                        const float* d_pos, const float* d_neg,
+                        void* ws, size_t ws_bytes, const mcrn_grads_t* grads, void* stream);
+
+/* ---- adaptive adjacency: model/MegaCRN.py:169-172 ---- */
+size_t mcrn_supports_workspace_bytes(int N, int M, int D);
+/* g1 = softmax(relu(E1 E2^T)), g2 = softmax(relu(E2 E1^T)); g1,g2 are (N,N) contiguous */
+int mcrn_supports_forward(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
+                          void* ws, size_t ws_bytes, float* g1, float* g2, void* stream);
+int mcrn_supports_backward(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
+                           const float* dg1, const float* dg2, void* ws, size_t ws_bytes,
+                           float* dWe1, float* dWe2, float* dMem, void* stream);
+
+/* ---- AGCN.forward: model/MegaCRN.py:16-28 ---- */
+size_t mcrn_agcn_workspace_bytes(int B, int N, int C, int O, int cheb_k);
+/* x (B,N,C), s1,s2 (N,N), W (2*cheb_k*C, O), b (O) -> y (B,N,O) */
+int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, const float* s1,
+                      const float* s2, const float* W, const float* b, void* ws, size_t ws_bytes,
+                      float* y, void* stream);
+int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, const float* s1,
+                       const float* s2, const float* W, void* ws, size_t ws_bytes, float* dx,
+                       float* ds1, float* ds2, float* dW, float* db, void* stream);
+
+/* ---- AGCRNCell.forward: model/MegaCRN.py:38-48 ---- */
+size_t mcrn_cell_workspace_bytes(int B, int N, int din, int H, int cheb_k);
+/* x (B,N,din), h (B,N,H) -> hn (B,N,H).  gate_w (2*cheb_k*(din+H), 2H), update_w (.., H) */
+int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, const float* h,
+                      const float* s1, const float* s2, const float* gate_w, const float* gate_b,
+                      const float* update_w, const float* update_b, void* ws, size_t ws_bytes,
+                      float* hn, void* stream);
+int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dhn, const float* s1,
+                       const float* s2, const float* gate_w, const float* update_w, void* ws,
+                       size_t ws_bytes, float* dx, float* dh, float* ds1, float* ds2,
+                       float* dgate_w, float* dgate_b, float* dupdate_w, float* dupdate_b,
+                       void* stream);
+
+/* ---- MegaCRN.query_memory: model/MegaCRN.py:159-166 ---- */
+size_t mcrn_memory_workspace_bytes(int B, int N, int H, int M, int D);
+/* h (B,N,H) -> value, query, pos, neg (B,N,D); ind (B,N,2) int32 top-2 indices */
+int mcrn_memory_forward(int B, int N, int H, int M, int D, const float* h, const float* Mem,
+                        const float* Wq, void* ws, size_t ws_bytes, float* value, float* query,
+                        float* pos, float* neg, int* ind, void* stream);
+int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, const float* Mem,
+                         const float* Wq, const float* dvalue, const float* dquery,
+                         const float* dpos, const float* dneg, void* ws, size_t ws_bytes,
+                         float* dh, float* dMem, float* dWq, void* stream);
+
+/* ---- trainer tail: clip_grad_norm_ + Adam on one flat fp32 buffer
+ *      (model/traintest_MegaCRN.py:104,129-130) ---- */
+/* p,g,m,v: flat arrays of n floats.  scratch: >= 1024 floats.  step is the 1-based Adam step.
+ * grad_scale multiplies g first (1/world_size after an all-reduce(sum)).  total_norm_out (device,
+ * 1 float, may be NULL) receives the pre-clip norm of grad_scale*g. */
+int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1,
+                        float beta2, float eps, int step, float max_norm, float grad_scale,
+                        float* scratch, float* total_norm_out, void* stream);
+
+/* ---- test hook: C = alpha*op(A)*op(B) + beta*C on the library's MFMA GEMM ---- */
+/* A is (M,K) row-major if !transA else (K,M); B is (K,N) if !transB else (N,K); C (M,N). */
+int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B,
+                  float* C, float alpha, float beta, int nsplit, float* slabs, void* stream);
+
+/* name and total launches of the last model forward+backward (for bench/roofline bookkeeping) */
+int mcrn_last_launch_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGACRN_HIP_H */

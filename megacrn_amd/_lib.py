@@ -1,0 +1,107 @@
+"""ctypes binding of libmegacrn_hip.so (C ABI declared in include/megacrn_hip.h).
+
+There is no CPU / eager fallback: if the library is missing, importing this module raises, and
+every wrapper raises ``RuntimeError`` when the C entry point returns non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmegacrn_hip.so")
+
+EXPORTS = [
+    "mcrn_last_error", "mcrn_version", "mcrn_last_launch_count",
+    "mcrn_model_workspace_bytes", "mcrn_model_forward", "mcrn_model_backward",
+    "mcrn_supports_workspace_bytes", "mcrn_supports_forward", "mcrn_supports_backward",
+    "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
+    "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
+    "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
+    "mcrn_flat_clip_adam", "mcrn_gemm_f32",
+]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "N", "T_in", "T_out", "input_dim", "output_dim", "ycov_dim",
+                                       "H", "mem_num", "mem_dim", "cheb_k", "precision")]
+
+
+PARAM_FIELDS = ("Memory", "Wq", "We1", "We2", "enc_gate_w", "enc_gate_b", "enc_update_w", "enc_update_b",
+                "dec_gate_w", "dec_gate_b", "dec_update_w", "dec_update_b", "proj_w", "proj_b")
+
+# state_dict key of each field (num_layers == 1), SURVEY.md 8(b)
+PARAM_KEYS = ("memory.Memory", "memory.Wq", "memory.We1", "memory.We2",
+              "encoder.dcrnn_cells.0.gate.weights", "encoder.dcrnn_cells.0.gate.bias",
+              "encoder.dcrnn_cells.0.update.weights", "encoder.dcrnn_cells.0.update.bias",
+              "decoder.dcrnn_cells.0.gate.weights", "decoder.dcrnn_cells.0.gate.bias",
+              "decoder.dcrnn_cells.0.update.weights", "decoder.dcrnn_cells.0.update.bias",
+              "proj.0.weight", "proj.0.bias")
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class Grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C megacrn_amd/csrc`.  megacrn_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} lacks symbols {missing}")
+    vp, i, f, sz, ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+    lib.mcrn_last_error.restype = C.c_char_p
+    lib.mcrn_version.restype = i
+    lib.mcrn_last_launch_count.restype = i
+    lib.mcrn_model_workspace_bytes.restype = sz
+    lib.mcrn_model_workspace_bytes.argtypes = [C.POINTER(Dims)]
+    lib.mcrn_model_forward.restype = i
+    lib.mcrn_model_forward.argtypes = [C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, C.POINTER(C.c_int),
+                                       vp, sz, vp, vp, vp, vp, vp, vp]
+    lib.mcrn_model_backward.restype = i
+    lib.mcrn_model_backward.argtypes = [C.POINTER(Dims), C.POINTER(Params), C.POINTER(C.c_int), vp, vp, vp, vp,
+                                        vp, vp, sz, C.POINTER(Grads), vp]
+    lib.mcrn_supports_workspace_bytes.restype = sz
+    lib.mcrn_supports_workspace_bytes.argtypes = [i, i, i]
+    lib.mcrn_supports_forward.restype = i
+    lib.mcrn_supports_forward.argtypes = [i, i, i, vp, vp, vp, vp, sz, vp, vp, vp]
+    lib.mcrn_supports_backward.restype = i
+    lib.mcrn_supports_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.mcrn_agcn_workspace_bytes.restype = sz
+    lib.mcrn_agcn_workspace_bytes.argtypes = [i] * 5
+    lib.mcrn_agcn_forward.restype = i
+    lib.mcrn_agcn_forward.argtypes = [i] * 5 + [vp] * 5 + [vp, sz, vp, vp]
+    lib.mcrn_agcn_backward.restype = i
+    lib.mcrn_agcn_backward.argtypes = [i] * 5 + [vp] * 4 + [vp, sz] + [vp] * 5 + [vp]
+    lib.mcrn_cell_workspace_bytes.restype = sz
+    lib.mcrn_cell_workspace_bytes.argtypes = [i] * 5
+    lib.mcrn_cell_forward.restype = i
+    lib.mcrn_cell_forward.argtypes = [i] * 5 + [vp] * 8 + [vp, sz, vp, vp]
+    lib.mcrn_cell_backward.restype = i
+    lib.mcrn_cell_backward.argtypes = [i] * 5 + [vp] * 5 + [vp, sz] + [vp] * 8 + [vp]
+    lib.mcrn_memory_workspace_bytes.restype = sz
+    lib.mcrn_memory_workspace_bytes.argtypes = [i] * 5
+    lib.mcrn_memory_forward.restype = i
+    lib.mcrn_memory_forward.argtypes = [i] * 5 + [vp] * 3 + [vp, sz] + [vp] * 5 + [vp]
+    lib.mcrn_memory_backward.restype = i
+    lib.mcrn_memory_backward.argtypes = [i] * 5 + [vp] * 7 + [vp, sz] + [vp] * 3 + [vp]
+    lib.mcrn_flat_clip_adam.restype = i
+    lib.mcrn_flat_clip_adam.argtypes = [vp, vp, vp, vp, ll, f, f, f, f, i, f, f, vp, vp, vp]
+    lib.mcrn_gemm_f32.restype = i
+    lib.mcrn_gemm_f32.argtypes = [i, i, i, i, i, vp, vp, vp, f, f, i, vp, vp]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib.mcrn_last_error().decode()}")

@@ -1,0 +1,1018 @@
+// engine.hip - host-side orchestration + C ABI of libmegacrn_hip.so  (see include/megacrn_hip.h)
+//
+// Data layout in HBM (all fp32):
+//   activations are NODE-MAJOR planes  Z[g][n][b][c]  (g = Chebyshev plane, row r = n*B + b,
+//   c < Cp = roundup(H + d_in, 4); channels [h | x | 0-pad]).  Plane g viewed as an
+//   (N x B*Cp) matrix is the right operand of the propagation GEMM  S x Z[g]; the same memory
+//   viewed as (N*B x G*Cp) is the left operand of the weight-pool GEMM.  Planes:
+//     g = 0            x                       (identity terms of both supports share it)
+//     g = 1 + s*(K-1)  S_s x                   (s = support 0/1)
+//     g = 2 + s*(K-1)  2 S_s (S_s x) - x       (cheb_k = 3)
+//   Per time step one Z (gate input [h | x]) and one Y (candidate input [z*h | x]) plane set is
+//   kept for the backward pass, plus zr = sigmoid(gate) and hc = tanh(update).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/megacrn_hip.h"
+#include "gemm_f32.h"
+#include "ops.h"
+
+namespace mcrn {
+
+GemmStats g_gemm_stats = {0, 0.0};
+static char g_err[512] = "";
+static int g_launches = 0;
+
+#define CK(expr)                                                                              \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            snprintf(g_err, sizeof g_err, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,       \
+                     hipGetErrorString(e__));                                                 \
+            return (int)e__;                                                                  \
+        }                                                                                     \
+    } while (0)
+#define CKI(expr)                                                                             \
+    do {                                                                                      \
+        int r__ = (expr);                                                                     \
+        if (r__ != 0) return r__;                                                             \
+    } while (0)
+#define FAIL(...)                                                                             \
+    do {                                                                                      \
+        snprintf(g_err, sizeof g_err, __VA_ARGS__);                                           \
+        return MCRN_EINVAL;                                                                   \
+    } while (0)
+#define LAUNCH(kern, grid, blk, shm, st, ...)                                                 \
+    do {                                                                                      \
+        hipLaunchKernelGGL(kern, grid, blk, shm, st, __VA_ARGS__);                            \
+        ++g_launches;                                                                         \
+        CK(hipGetLastError());                                                                \
+    } while (0)
+
+static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, hipStream_t st) {
+    if (!p.nbatch) p.nbatch = 1;
+    for (int b = 0; b < 2; ++b) {   // per-batch hi strides default to the Dim2 value
+        if (!p.ak_hi[b]) p.ak_hi[b] = p.ak.hi;
+        if (!p.bk_hi[b]) p.bk_hi[b] = p.bk.hi;
+    }
+    ++g_launches;
+    CK(launch_gemm(p, akc, bkc, max_split, st));
+    return 0;
+}
+
+// ---- bump allocator over the caller's workspace -------------------------------------------
+struct Bump {
+    char* base;
+    size_t off;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : (T*)nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct Shp {   // one AGCN / cell geometry
+    int B, N, d, H, C, Cp, K, G;
+    long long R, ld, PS, ZT;   // rows, plane row stride (per node), plane size, plane-set size
+};
+static Shp mk_shape(int B, int N, int d, int H, int K) {
+    Shp s;
+    s.B = B; s.N = N; s.d = d; s.H = H; s.K = K;
+    s.C = d + H;
+    s.Cp = (s.C + 3) & ~3;
+    s.G = 2 * K - 1;
+    s.R = (long long)N * B;
+    s.ld = (long long)B * s.Cp;
+    s.PS = s.R * s.Cp;
+    s.ZT = s.PS * s.G;
+    return s;
+}
+
+struct Sup {   // the two supports, their transposes, and the slabbed gradient accumulators
+    const float* S[2];
+    const float* St[2];
+    long long ldS;
+    float* dS;      // [2][nslab][N*ldS]
+    int nslab;
+    long long slab;
+};
+static int nslab_S(int N) { return N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1)); }
+static const int NSLAB_W = 64;
+
+static GemmP gp() {
+    GemmP p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f;
+    p.nbatch = 1;
+    p.nsplit = 1;
+    return p;
+}
+
+// ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
+static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
+    GemmP p = gp();
+    p.M = s.N; p.N = (int)s.ld; p.K = s.N;
+    p.am = plain(u.ldS); p.ak = plain(1);
+    p.bk = plain(s.ld);  p.bn = plain(1);
+    p.cm = plain(s.ld);  p.cn = plain(1);
+    p.nbatch = 2;
+    for (int b = 0; b < 2; ++b) {
+        p.A[b] = u.S[b];
+        p.B[b] = Z;
+        p.C[b] = Z + (1 + b * (s.K - 1)) * s.PS;
+        p.Cin[b] = nullptr;
+    }
+    CKI(gemm(p, true, false, 0, st));
+    if (s.K == 3) {   // x2 = 2 S x1 - x0
+        for (int b = 0; b < 2; ++b) {
+            p.B[b] = Z + (1 + 2 * b) * s.PS;
+            p.C[b] = Z + (2 + 2 * b) * s.PS;
+            p.Cin[b] = Z;
+        }
+        p.alpha = 2.f; p.beta = -1.f;
+        CKI(gemm(p, true, false, 0, st));
+    }
+    return 0;
+}
+
+// ---- weight pool with fused epilogue:  out = epi([Z planes] @ Wf + b)   (MegaCRN.py:26-27) ----
+static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP epi, hipStream_t st) {
+    GemmP p = epi;
+    p.M = (int)s.R; p.N = O; p.K = s.G * s.Cp;
+    p.A[0] = Z; p.B[0] = Wf;
+    p.am = plain(s.Cp); p.ak = two(s.Cp, s.PS, 1); p.ak_hi[0] = s.PS;
+    p.bk = plain(O); p.bn = plain(1);
+    return gemm(p, true, false, 0, st);
+}
+
+// ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
+static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
+                         const float* X, float* dP, hipStream_t st) {
+    {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
+        GemmP p = gp();
+        p.M = (int)s.R; p.N = s.G * s.Cp; p.K = O;
+        p.A[0] = dY; p.am = plain(O); p.ak = plain(1);
+        p.B[0] = Wd; p.bk = plain(1); p.bn = plain(O);
+        p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
+        CKI(gemm(p, true, true, 0, st));
+    }
+    if (s.K == 3) {   // d1 += S^T e2     (e2 = 2 d2, folded into Wd)
+        GemmP p = gp();
+        p.M = s.N; p.N = (int)s.ld; p.K = s.N;
+        p.am = plain(u.ldS); p.ak = plain(1);
+        p.bk = plain(s.ld); p.bn = plain(1);
+        p.cm = plain(s.ld); p.cn = plain(1);
+        p.nbatch = 2; p.beta = 1.f;
+        for (int b = 0; b < 2; ++b) {
+            p.A[b] = u.St[b];
+            p.B[b] = dP + (2 + 2 * b) * s.PS;
+            p.C[b] = dP + (1 + 2 * b) * s.PS;
+            p.Cin[b] = p.C[b];
+        }
+        CKI(gemm(p, true, false, 0, st));
+    }
+    {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
+        GemmP p = gp();
+        const int nk = s.K == 3 ? 2 : 1;
+        p.M = s.N; p.N = s.N; p.K = (int)(nk * s.ld);
+        p.am = plain(s.ld); p.ak = two((int)s.ld, s.PS, 1);
+        p.bn = plain(s.ld); p.bk = two((int)s.ld, 0, 1);
+        p.cm = plain(u.ldS); p.cn = plain(1);
+        p.nbatch = 2; p.beta = 1.f; p.slab = u.slab;
+        for (int b = 0; b < 2; ++b) {
+            const long long g1 = 1 + b * (s.K - 1);
+            p.A[b] = dP + g1 * s.PS; p.ak_hi[b] = s.PS;
+            p.B[b] = X;              p.bk_hi[b] = g1 * s.PS;
+            p.C[b] = u.dS + (long long)b * u.nslab * u.slab;
+            p.Cin[b] = p.C[b];
+        }
+        CKI(gemm(p, true, true, u.nslab, st));
+    }
+    {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b
+        GemmP p = gp();
+        p.M = s.N; p.N = (int)s.ld; p.K = 2 * s.N;
+        p.A[0] = u.St[0]; p.am = plain(u.ldS);
+        p.ak = two(s.N, 0, 1); p.ak_hi[0] = (long long)(u.St[1] - u.St[0]);
+        p.B[0] = dP + s.PS; p.bk = two(s.N, 0, s.ld); p.bk_hi[0] = (long long)(s.K - 1) * s.PS;
+        p.bn = plain(1);
+        p.C[0] = dP; p.Cin[0] = dP; p.cm = plain(s.ld); p.cn = plain(1);
+        p.beta = 1.f;
+        CKI(gemm(p, true, false, 0, st));
+    }
+    return 0;
+}
+
+// ---- deferred weight gradient: slabs += X_all^T dY_all over T steps -------------------------------
+static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
+                      int O, float* slabs, hipStream_t st) {
+    GemmP p = gp();
+    p.M = s.G * s.Cp; p.N = O; p.K = (int)(T * s.R);
+    p.A[0] = Xall; p.am = two(s.Cp, s.PS, 1);
+    p.ak = two((int)s.R, step_stride, s.Cp); p.ak_hi[0] = step_stride;
+    p.B[0] = dYall; p.bk = plain(O); p.bn = plain(1);
+    p.C[0] = slabs; p.Cin[0] = slabs; p.cm = plain(O); p.cn = plain(1);
+    p.beta = 1.f; p.slab = (long long)s.G * s.Cp * O;
+    return gemm(p, false, false, NSLAB_W, st);
+}
+
+static int colsum(const float* X, long long ld, long long rows, int C, float* part, float* out,
+                  int accumulate, hipStream_t st) {
+    const int chunk = 256;
+    int nblk = cdiv(rows, chunk);
+    LAUNCH(k_colsum_stage1, dim3(nblk), dim3(256), 0, st, X, ld, rows, C, chunk, part);
+    LAUNCH(k_colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)part, nblk, C, out, accumulate);
+    return 0;
+}
+static size_t colsum_part_floats(long long rows, int C) { return (size_t)cdiv(rows, 256) * C; }
+
+// ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
+struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; };
+
+static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* zr, float* hc,
+                         const CellW& w, float* hnext, long long hnext_ld, hipStream_t st) {
+    CKI(prop_fwd(s, u, Z, st));
+    GemmP e = gp();
+    e.epi = EPI_GATE; e.C[0] = zr; e.bias = w.bg; e.hsrc = Z; e.hsrc_ld = s.Cp;
+    e.out2 = Y; e.out2_ld = s.Cp; e.H = s.H;
+    CKI(wp_fwd(s, Z, w.Wf_g, 2 * s.H, e, st));
+    CKI(prop_fwd(s, u, Y, st));
+    e = gp();
+    e.epi = EPI_UPDATE; e.C[0] = hc; e.bias = w.bu; e.hsrc = Z; e.hsrc_ld = s.Cp; e.zr = zr;
+    e.out2 = hnext; e.out2_ld = hnext_ld; e.H = s.H;
+    CKI(wp_fwd(s, Y, w.Wf_u, s.H, e, st));
+    return 0;
+}
+
+static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float* Y, const float* zr,
+                         const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
+                         float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st) {
+    const long long RH = s.R * s.H;
+    LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st));
+    LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st));
+    LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dP, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    return 0;
+}
+
+// ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; };
+static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
+    size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
+    o.ldS = ldS;
+    o.E1 = b.take<float>(nd); o.E2 = b.take<float>(nd);
+    o.L1 = b.take<float>(nn); o.L2 = b.take<float>(nn);
+    o.g1 = b.take<float>(nn); o.g2 = b.take<float>(nn);
+    o.St1 = b.take<float>(nn); o.St2 = b.take<float>(nn);
+    o.dLa = b.take<float>(nn); o.dLb = b.take<float>(nn); o.dLs = b.take<float>(nn);
+    o.dE1 = b.take<float>(nd); o.dE2 = b.take<float>(nd);
+}
+static int transpose(float* dst, long long ldd, const float* src, long long lds_, const float* add,
+                     long long lda, int N, hipStream_t st) {
+    dim3 g(cdiv(N, 32), cdiv(N, 32));
+    LAUNCH(k_transpose_add, g, dim3(256), 0, st, dst, ldd, src, lds_, add, lda, N);
+    return 0;
+}
+static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
+                        const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st) {
+    for (int i = 0; i < 2; ++i) {   // E = We Mem
+        GemmP p = gp();
+        p.M = N; p.N = D; p.K = M;
+        p.A[0] = i ? We2 : We1; p.am = plain(M); p.ak = plain(1);
+        p.B[0] = Mem; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = i ? o.E2 : o.E1; p.cm = plain(D); p.cn = plain(1);
+        CKI(gemm(p, true, false, 0, st));
+    }
+    {   // L1 = E1 E2^T
+        GemmP p = gp();
+        p.M = N; p.N = N; p.K = D;
+        p.A[0] = o.E1; p.am = plain(D); p.ak = plain(1);
+        p.B[0] = o.E2; p.bk = plain(1); p.bn = plain(D);
+        p.C[0] = o.L1; p.cm = plain(o.ldS); p.cn = plain(1);
+        CKI(gemm(p, true, true, 0, st));
+    }
+    CKI(transpose(o.L2, o.ldS, o.L1, o.ldS, nullptr, 0, N, st));
+    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, N);
+    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, N);
+    if (want_T) {
+        CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
+        CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
+    }
+    return 0;
+}
+// dS given as slabs; g1,g2 as saved; writes dWe1,dWe2 directly and accumulates dMem into dMem_slab0 (+=)
+static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
+                        const SupBufs& o, const float* g1, const float* g2, long long ldg,
+                        const float* dS1, const float* dS2, long long ldd, int nslab, long long slab,
+                        float* dWe1, float* dWe2, float* dMem_acc, hipStream_t st) {
+    LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, dS1, ldd, nslab, slab, o.dLa, o.ldS, N);
+    LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, dS2, ldd, nslab, slab, o.dLb, o.ldS, N);
+    CKI(transpose(o.dLs, o.ldS, o.dLb, o.ldS, o.dLa, o.ldS, N, st));   // dLs = dL1 + dL2^T
+    {   // dE1 = dLs E2
+        GemmP p = gp();
+        p.M = N; p.N = D; p.K = N;
+        p.A[0] = o.dLs; p.am = plain(o.ldS); p.ak = plain(1);
+        p.B[0] = o.E2; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = o.dE1; p.cm = plain(D); p.cn = plain(1);
+        CKI(gemm(p, true, false, 0, st));
+    }
+    {   // dE2 = dLs^T E1
+        GemmP p = gp();
+        p.M = N; p.N = D; p.K = N;
+        p.A[0] = o.dLs; p.am = plain(1); p.ak = plain(o.ldS);
+        p.B[0] = o.E1; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = o.dE2; p.cm = plain(D); p.cn = plain(1);
+        CKI(gemm(p, false, false, 0, st));
+    }
+    for (int i = 0; i < 2; ++i) {
+        {   // dWe = dE Mem^T
+            GemmP p = gp();
+            p.M = N; p.N = M; p.K = D;
+            p.A[0] = i ? o.dE2 : o.dE1; p.am = plain(D); p.ak = plain(1);
+            p.B[0] = Mem; p.bk = plain(1); p.bn = plain(D);
+            p.C[0] = i ? dWe2 : dWe1; p.cm = plain(M); p.cn = plain(1);
+            CKI(gemm(p, true, true, 0, st));
+        }
+        {   // dMem += We^T dE
+            GemmP p = gp();
+            p.M = M; p.N = D; p.K = N;
+            p.A[0] = i ? We2 : We1; p.am = plain(1); p.ak = plain(M);
+            p.B[0] = i ? o.dE2 : o.dE1; p.bk = plain(D); p.bn = plain(1);
+            p.C[0] = dMem_acc; p.Cin[0] = dMem_acc; p.cm = plain(D); p.cn = plain(1);
+            p.beta = 1.f;
+            CKI(gemm(p, false, false, 0, st));
+        }
+    }
+    return 0;
+}
+
+// ---- plane-0 packing helpers ------------------------------------------------------------------
+static int fill_cols(float* dst, long long dst_t, int Cp, int col0, int w, const float* src, long long sb,
+                     long long stt, long long sn, int B, int N, int T, hipStream_t st) {
+    if (w <= 0 || T <= 0) return 0;
+    long long tot = (long long)T * N * B * w;
+    LAUNCH(k_fill_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, dst, dst_t, Cp, col0, w, src, sb, stt, sn, B, N, T);
+    return 0;
+}
+static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long long R, int T, hipStream_t st) {
+    if (c1 <= c0 || T <= 0) return 0;
+    long long tot = (long long)T * R * (c1 - c0);
+    LAUNCH(k_zero_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, dst, dst_t, Cp, c0, c1, R, T);
+    return 0;
+}
+static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st) {
+    long long tot = (long long)s.G * s.Cp * O;
+    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O);
+    return 0;
+}
+static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st) {
+    long long tot = (long long)2 * s.K * s.C * O;
+    LAUNCH(k_wunprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, dW, slabs, NSLAB_W, (long long)s.G * s.Cp * O, s.d, s.H, s.Cp, s.K, O);
+    return 0;
+}
+
+// =================================================================================================
+// whole model
+// =================================================================================================
+struct ModelPlan {
+    Shp se, sd;
+    long long ldS;
+    int nslabS;
+    SupBufs sup;
+    float *dS;                               // [2][nslabS][N*ldS]
+    float *Wf[4], *Wd[4], *dWs[4];           // enc gate, enc update, dec gate, dec update
+    float *Zenc, *Yenc, *zr_e, *hc_e;
+    float *Zdec, *Ydec, *zr_d, *hc_d;
+    float *q_rows, *att_rows; int* ind_rows;
+    float *dP, *dQ;
+    float *dU_e, *dG_e, *dU_d, *dG_d;
+    float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
+    float *dval, *dsc, *dq;
+    float *dWq_s, *dMem_s, *dWp_s;
+    float *part;
+    size_t total;
+};
+
+static int check_dims(const mcrn_dims_t* d) {
+    if (!d) FAIL("dims is NULL");
+    if (d->B < 1 || d->N < 1 || d->T_in < 1 || d->T_out < 1 || d->input_dim < 1 || d->output_dim < 1 ||
+        d->ycov_dim < 0 || d->H < 1 || d->mem_num < 1 || d->mem_dim < 1)
+        FAIL("mcrn_dims: all sizes must be >= 1");
+    if (d->cheb_k != 2 && d->cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", d->cheb_k);
+    if (d->precision != MCRN_F32) FAIL("unsupported precision %d", d->precision);
+    return 0;
+}
+
+static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
+    Bump b{base, 0};
+    const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num, K = d->cheb_k;
+    const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim;
+    P.se = mk_shape(B, N, d->input_dim, H, K);
+    P.sd = mk_shape(B, N, od + yd, Hd, K);
+    P.ldS = (N + 3) & ~3;
+    P.nslabS = nslab_S(N);
+    plan_sup(b, N, M, D, P.ldS, P.sup);
+    P.dS = b.take<float>((size_t)2 * P.nslabS * N * P.ldS);
+    const Shp* sh[4] = {&P.se, &P.se, &P.sd, &P.sd};
+    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
+    for (int i = 0; i < 4; ++i) {
+        size_t n = (size_t)sh[i]->G * sh[i]->Cp * Os[i];
+        P.Wf[i] = b.take<float>(n);
+        P.Wd[i] = b.take<float>(n);
+        P.dWs[i] = b.take<float>(n * NSLAB_W);
+    }
+    const long long R = P.se.R;
+    P.Zenc = b.take<float>((size_t)(d->T_in + 1) * P.se.ZT);
+    P.Yenc = b.take<float>((size_t)d->T_in * P.se.ZT);
+    P.zr_e = b.take<float>((size_t)d->T_in * R * 2 * H);
+    P.hc_e = b.take<float>((size_t)d->T_in * R * H);
+    P.Zdec = b.take<float>((size_t)(d->T_out + 1) * P.sd.ZT);
+    P.Ydec = b.take<float>((size_t)d->T_out * P.sd.ZT);
+    P.zr_d = b.take<float>((size_t)d->T_out * R * 2 * Hd);
+    P.hc_d = b.take<float>((size_t)d->T_out * R * Hd);
+    P.q_rows = b.take<float>((size_t)R * D);
+    P.att_rows = b.take<float>((size_t)R * M);
+    P.ind_rows = b.take<int>((size_t)R * 2);
+    size_t zmax = (size_t)(P.se.ZT > P.sd.ZT ? P.se.ZT : P.sd.ZT);
+    P.dP = b.take<float>(zmax);
+    P.dQ = b.take<float>(zmax);
+    P.dU_e = b.take<float>((size_t)d->T_in * R * H);
+    P.dG_e = b.take<float>((size_t)d->T_in * R * 2 * H);
+    P.dU_d = b.take<float>((size_t)d->T_out * R * Hd);
+    P.dG_d = b.take<float>((size_t)d->T_out * R * 2 * Hd);
+    P.dacc_e = b.take<float>((size_t)R * H);
+    P.dacc_d = b.take<float>((size_t)R * Hd);
+    P.dhn_d = b.take<float>((size_t)R * Hd);
+    P.dxin_e = b.take<float>((size_t)R * d->input_dim);
+    P.dxin_d = b.take<float>((size_t)R * (od + yd));
+    P.dgo = b.take<float>((size_t)d->T_out * R * od);
+    P.dval = b.take<float>((size_t)R * D);
+    P.dsc = b.take<float>((size_t)R * M);
+    P.dq = b.take<float>((size_t)R * D);
+    P.dWq_s = b.take<float>((size_t)NSLAB_W * H * D);
+    P.dMem_s = b.take<float>((size_t)NSLAB_W * M * D);
+    P.dWp_s = b.take<float>((size_t)NSLAB_W * od * Hd);
+    int Tm = d->T_in > d->T_out ? d->T_in : d->T_out;
+    P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
+    P.total = (b.off + 255) & ~(size_t)255;
+}
+
+static Sup model_sup(const ModelPlan& P, int N) {
+    Sup u;
+    u.S[0] = P.sup.g1; u.S[1] = P.sup.g2;
+    u.St[0] = P.sup.St1; u.St[1] = P.sup.St2;
+    u.ldS = P.ldS;
+    u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
+    return u;
+}
+
+static int memory_fwd_launch(const float* h, long long ldh, const float* Wq, const float* Mem, int B, int N,
+                             int H, int M, int D, float* q_rows, float* att_rows, int* ind_rows, float* s0,
+                             long long lds0, float* val, float* q, float* pos, float* neg, int* ind_bnc,
+                             hipStream_t st) {
+    const int nt = 64;
+    size_t shm = ((size_t)H * D + (size_t)M * D + (size_t)(D + M) * nt) * sizeof(float);
+    if (shm > 160 * 1024) FAIL("memory head too large for LDS (H*D + M*D + 64*(D+M) floats = %zu bytes)", shm);
+    if (shm > 64 * 1024)
+        CK(hipFuncSetAttribute((const void*)k_memory_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    LAUNCH(k_memory_fwd, dim3(cdiv((long long)N * B, nt)), dim3(nt), shm, st, h, ldh, Wq, Mem, B, N, H, M, D,
+           q_rows, att_rows, ind_rows, s0, lds0, val, q, pos, neg, ind_bnc);
+    return 0;
+}
+static int memory_bwd_rows_launch(const float* dval_rows, long long ldv, int c0, const float* dval_bnc,
+                                  const float* dq_bnc, const float* att_rows, const float* Mem, int B, int N,
+                                  int M, int D, float* dval_out, float* dsc, float* dq, hipStream_t st) {
+    const int nt = 64;
+    size_t shm = ((size_t)M * D + (size_t)(D + M) * nt) * sizeof(float);
+    if (shm > 160 * 1024) FAIL("memory head too large for LDS");
+    if (shm > 64 * 1024)
+        CK(hipFuncSetAttribute((const void*)k_memory_bwd_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    LAUNCH(k_memory_bwd_rows, dim3(cdiv((long long)N * B, nt)), dim3(nt), shm, st, dval_rows, ldv, c0, dval_bnc,
+           dq_bnc, att_rows, Mem, B, N, M, D, dval_out, dsc, dq);
+    return 0;
+}
+// dh (+)= dq Wq^T ; dWq slabs += h^T dq ; dMem slabs += att^T dval + dsc^T q
+static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long long R, int H, int M, int D,
+                            const float* att, const float* q_rows, const float* dval, const float* dsc,
+                            const float* dq, float* dh, long long lddh, bool dh_accumulate, float* dWq_s,
+                            float* dMem_s, hipStream_t st) {
+    {
+        GemmP p = gp();
+        p.M = (int)R; p.N = H; p.K = D;
+        p.A[0] = dq; p.am = plain(D); p.ak = plain(1);
+        p.B[0] = Wq; p.bk = plain(1); p.bn = plain(D);
+        p.C[0] = dh; p.cm = plain(lddh); p.cn = plain(1);
+        if (dh_accumulate) { p.Cin[0] = dh; p.beta = 1.f; }
+        CKI(gemm(p, true, true, 0, st));
+    }
+    {
+        GemmP p = gp();
+        p.M = H; p.N = D; p.K = (int)R;
+        p.A[0] = h; p.am = plain(1); p.ak = plain(ldh);
+        p.B[0] = dq; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = dWq_s; p.Cin[0] = dWq_s; p.cm = plain(D); p.cn = plain(1);
+        p.beta = 1.f; p.slab = (long long)H * D;
+        CKI(gemm(p, false, false, NSLAB_W, st));
+    }
+    for (int i = 0; i < 2; ++i) {
+        GemmP p = gp();
+        p.M = M; p.N = D; p.K = (int)R;
+        p.A[0] = i ? dsc : att; p.am = plain(1); p.ak = plain(M);
+        p.B[0] = i ? q_rows : dval; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = dMem_s; p.Cin[0] = dMem_s; p.cm = plain(D); p.cn = plain(1);
+        p.beta = 1.f; p.slab = (long long)M * D;
+        CKI(gemm(p, false, false, NSLAB_W, st));
+    }
+    return 0;
+}
+
+static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float* x, const float* ycov,
+                         const float* labels, const int* teacher, char* ws, float* output, float* h_att,
+                         float* query, float* pos, float* neg, hipStream_t st) {
+    ModelPlan P;
+    plan_model(d, ws, P);
+    const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num;
+    const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim, din = d->input_dim;
+    const int Ti = d->T_in, To = d->T_out;
+    const Shp &se = P.se, &sd = P.sd;
+    const long long R = se.R;
+    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, true, st));
+    Sup u = model_sup(P, N);
+    const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
+    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
+    for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], st));
+    // ---- encoder (MegaCRN.py:65-83): inputs for all t packed once
+    CKI(fill_cols(P.Zenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
+    CKI(fill_cols(P.Yenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
+    CKI(zero_cols(P.Zenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
+    CKI(zero_cols(P.Yenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
+    CKI(zero_cols(P.Zenc, se.ZT, se.Cp, 0, H, R, 1, st));   // init_hidden = 0 (:50-51)
+    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b};
+    for (int t = 0; t < Ti; ++t)
+        CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
+                          we, P.Zenc + (t + 1) * se.ZT, se.Cp, st));
+    // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
+    CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
+                          P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
+    // ---- decoder (:181-192)
+    if (yd > 0) {
+        CKI(fill_cols(P.Zdec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, st));
+        CKI(fill_cols(P.Ydec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, st));
+    }
+    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, st));
+    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, st));
+    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));   // go = 0 (:182)
+    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));
+    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b};
+    for (int t = 0; t < To; ++t) {
+        float* Zn = P.Zdec + (t + 1) * sd.ZT;
+        CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
+                          P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st));
+        const bool last = t + 1 == To;
+        const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;
+        LAUNCH(k_proj_fwd, dim3(cdiv(R, 4) < 2048 ? cdiv(R, 4) : 2048), dim3(256), 0, st, (const float*)Zn,
+               (long long)sd.Cp, p->proj_w, p->proj_b, Hd, od, B, N, output + (long long)t * N * od,
+               (long long)To * N * od, (long long)od, last ? (float*)nullptr : Zn,
+               last ? (float*)nullptr : P.Ydec + (t + 1) * sd.ZT, (long long)sd.Cp, Hd, lab);
+    }
+    return 0;
+}
+
+static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher,
+                          const float* d_output, const float* d_hatt, const float* d_query, const float* d_pos,
+                          const float* d_neg, char* ws, const mcrn_grads_t* g, hipStream_t st) {
+    ModelPlan P;
+    plan_model(d, ws, P);
+    const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num;
+    const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim;
+    const int Ti = d->T_in, To = d->T_out;
+    const Shp &se = P.se, &sd = P.sd;
+    const long long R = se.R;
+    Sup u = model_sup(P, N);
+    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
+    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * P.ldS * sizeof(float), st));
+    for (int i = 0; i < 4; ++i)
+        CK(hipMemsetAsync(P.dWs[i], 0, (size_t)(i < 2 ? se : sd).G * (i < 2 ? se : sd).Cp * Os[i] * NSLAB_W * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_W * od * Hd * sizeof(float), st));
+    // ---- decoder BPTT
+    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b};
+    for (int t = To - 1; t >= 0; --t) {
+        const bool last = t == To - 1;
+        const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
+        LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
+               (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
+               p->proj_w, Hd, od, B, N, last ? (const float*)nullptr : (const float*)P.dacc_d, P.dhn_d,
+               P.dgo + (long long)t * R * od);
+        CKI(cell_bwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
+                          wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dP, P.dQ, P.dacc_d, P.dxin_d, st));
+    }
+    {   // proj grads: dWp[j][c] = sum_{t,r} dgo[t][r][j] * h'_t[r][c]  (h'_t lives in Zdec[t+1])
+        GemmP q = gp();
+        q.M = od; q.N = Hd; q.K = (int)(To * R);
+        q.A[0] = P.dgo; q.am = plain(1); q.ak = plain(od);
+        q.B[0] = P.Zdec + sd.ZT; q.bk = two((int)R, sd.ZT, sd.Cp); q.bk_hi[0] = sd.ZT; q.bn = plain(1);
+        q.C[0] = P.dWp_s; q.Cin[0] = P.dWp_s; q.cm = plain(Hd); q.cn = plain(1);
+        q.beta = 1.f; q.slab = (long long)od * Hd;
+        CKI(gemm(q, false, false, NSLAB_W, st));
+        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, st, g->proj_w, (const float*)P.dWp_s, NSLAB_W,
+               (long long)od * Hd, (long long)od * Hd, 0);
+        CKI(colsum(P.dgo, od, To * R, od, P.part, g->proj_b, 0, st));
+    }
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], st));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], st));
+    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, st));
+    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, st));
+    CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, P.part, g->dec_gate_b, 0, st));
+    CKI(colsum(P.dU_d, Hd, To * R, Hd, P.part, g->dec_update_b, 0, st));
+    // ---- memory head backward: dacc_d = d[h_t | value]
+    CKI(memory_bwd_rows_launch(P.dacc_d, Hd, H, d_hatt, d_query, P.att_rows, p->Memory, B, N, M, D, P.dval, P.dsc, P.dq, st));
+    LAUNCH(k_copy2d, dim3(cdiv(R * H, 256)), dim3(256), 0, st, P.dacc_e, (long long)H, (const float*)P.dacc_d, (long long)Hd, R, H);
+    CKI(memory_bwd_gemms(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, R, H, M, D, P.att_rows, P.q_rows, P.dval, P.dsc, P.dq,
+                         P.dacc_e, H, true, P.dWq_s, P.dMem_s, st));
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_W,
+           (long long)H * D, (long long)H * D, 0);
+    // ---- encoder BPTT
+    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b};
+    for (int t = Ti - 1; t >= 0; --t)
+        CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
+                          P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dP, P.dQ, P.dacc_e, P.dxin_e, st));
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st));
+    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st));
+    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st));
+    CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
+    CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
+    // ---- adjacency backward (all dS contributions are in the slabs now)
+    CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS,
+                     P.dS + (long long)P.nslabS * u.slab, P.ldS, P.nslabS, u.slab, g->We1, g->We2, P.dMem_s, st));
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_W,
+           (long long)M * D, (long long)M * D, 0);
+    if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
+    if (d_neg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 1, d_neg, B, N, D);
+    return 0;
+}
+
+// =================================================================================================
+// stand-alone ops (batch-major boundary; pack -> node-major core -> unpack)
+// =================================================================================================
+struct CellPlan {
+    Shp s;
+    float *Z, *Y, *zr, *hc, *hn_rows;
+    float *Wf[2], *Wd[2], *dWs[2];
+    float *St1, *St2, *dS;
+    int nslabS;
+    float *dP, *dQ, *dU, *dG, *dacc, *dxin, *part;
+    size_t total;
+};
+static void plan_cell(int B, int N, int din, int H, int K, char* base, CellPlan& P) {
+    Bump b{base, 0};
+    P.s = mk_shape(B, N, din, H, K);
+    const Shp& s = P.s;
+    P.Z = b.take<float>((size_t)s.ZT); P.Y = b.take<float>((size_t)s.ZT);
+    P.zr = b.take<float>((size_t)s.R * 2 * H); P.hc = b.take<float>((size_t)s.R * H);
+    P.hn_rows = b.take<float>((size_t)s.R * H);
+    const int Os[2] = {2 * H, H};
+    for (int i = 0; i < 2; ++i) {
+        size_t n = (size_t)s.G * s.Cp * Os[i];
+        P.Wf[i] = b.take<float>(n); P.Wd[i] = b.take<float>(n); P.dWs[i] = b.take<float>(n * NSLAB_W);
+    }
+    P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
+    P.nslabS = nslab_S(N);
+    P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
+    P.dP = b.take<float>((size_t)s.ZT); P.dQ = b.take<float>((size_t)s.ZT);
+    P.dU = b.take<float>((size_t)s.R * H); P.dG = b.take<float>((size_t)s.R * 2 * H);
+    P.dacc = b.take<float>((size_t)s.R * H); P.dxin = b.take<float>((size_t)s.R * (din > 0 ? din : 1));
+    P.part = b.take<float>(colsum_part_floats(s.R, 2 * H) + 1024);
+    P.total = (b.off + 255) & ~(size_t)255;
+}
+static int bnc_to_rows(float* dst, long long ld, int col0, int w, const float* src, int B, int N, hipStream_t st) {
+    if (w <= 0) return 0;
+    LAUNCH(k_bnc_to_rows, dim3(cdiv((long long)B * N * w, 256)), dim3(256), 0, st, dst, ld, col0, w, src, B, N);
+    return 0;
+}
+static int rows_to_bnc(float* dst, const float* src, long long ld, int col0, int w, int B, int N, hipStream_t st) {
+    if (w <= 0) return 0;
+    LAUNCH(k_rows_to_bnc, dim3(cdiv((long long)B * N * w, 256)), dim3(256), 0, st, dst, src, ld, col0, w, B, N, 0);
+    return 0;
+}
+
+struct AgcnPlan {
+    Shp s;
+    float *Z, *y_rows, *Wf, *Wd, *dWs, *St1, *St2, *dS, *dP, *dY, *part;
+    int nslabS;
+    size_t total;
+};
+static void plan_agcn(int B, int N, int C, int O, int K, char* base, AgcnPlan& P) {
+    Bump b{base, 0};
+    P.s = mk_shape(B, N, 0, C, K);
+    const Shp& s = P.s;
+    P.Z = b.take<float>((size_t)s.ZT);
+    P.y_rows = b.take<float>((size_t)s.R * O);
+    size_t n = (size_t)s.G * s.Cp * O;
+    P.Wf = b.take<float>(n); P.Wd = b.take<float>(n); P.dWs = b.take<float>(n * NSLAB_W);
+    P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
+    P.nslabS = nslab_S(N);
+    P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
+    P.dP = b.take<float>((size_t)s.ZT);
+    P.dY = b.take<float>((size_t)s.R * O);
+    P.part = b.take<float>(colsum_part_floats(s.R, O) + 1024);
+    P.total = (b.off + 255) & ~(size_t)255;
+}
+
+struct MemPlan {
+    float *h_rows, *q_rows, *att, *dval, *dsc, *dq, *dh_rows, *dWq_s, *dMem_s;
+    int* ind;
+    size_t total;
+};
+static void plan_mem(int B, int N, int H, int M, int D, char* base, MemPlan& P) {
+    Bump b{base, 0};
+    size_t R = (size_t)B * N;
+    P.h_rows = b.take<float>(R * H); P.q_rows = b.take<float>(R * D); P.att = b.take<float>(R * M);
+    P.ind = b.take<int>(R * 2);
+    P.dval = b.take<float>(R * D); P.dsc = b.take<float>(R * M); P.dq = b.take<float>(R * D);
+    P.dh_rows = b.take<float>(R * H);
+    P.dWq_s = b.take<float>((size_t)NSLAB_W * H * D); P.dMem_s = b.take<float>((size_t)NSLAB_W * M * D);
+    P.total = (b.off + 255) & ~(size_t)255;
+}
+
+}  // namespace mcrn
+
+using namespace mcrn;
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* mcrn_last_error(void) { return g_err; }
+int mcrn_version(void) { return 100; }
+int mcrn_last_launch_count(void) { return g_launches; }
+
+size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d) {
+    if (check_dims(d)) return 0;
+    ModelPlan P;
+    plan_model(d, nullptr, P);
+    return P.total;
+}
+
+int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float* x, const float* ycov,
+                       const float* labels, const int* teacher, void* ws, size_t ws_bytes, float* output,
+                       float* h_att, float* query, float* pos, float* neg, void* stream) {
+    CKI(check_dims(d));
+    if (!p || !x || !ws || !output || !h_att || !query || !pos || !neg) FAIL("mcrn_model_forward: NULL argument");
+    if (d->ycov_dim > 0 && !ycov) FAIL("mcrn_model_forward: ycov is NULL");
+    if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small: %zu < %zu", ws_bytes, mcrn_model_workspace_bytes(d));
+    if (teacher && !labels) for (int t = 0; t < d->T_out; ++t) if (teacher[t]) FAIL("teacher forcing requested without labels");
+    g_launches = 0;
+    return model_forward(d, p, x, ycov, labels, teacher, (char*)ws, output, h_att, query, pos, neg, (hipStream_t)stream);
+}
+
+int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher, const float* d_output,
+                        const float* d_hatt, const float* d_query, const float* d_pos, const float* d_neg, void* ws,
+                        size_t ws_bytes, const mcrn_grads_t* grads, void* stream) {
+    CKI(check_dims(d));
+    if (!p || !d_output || !ws || !grads) FAIL("mcrn_model_backward: NULL argument");
+    if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small");
+    return model_backward(d, p, teacher, d_output, d_hatt, d_query, d_pos, d_neg, (char*)ws, grads, (hipStream_t)stream);
+}
+
+// ---- supports -----------------------------------------------------------------------------------
+size_t mcrn_supports_workspace_bytes(int N, int M, int D) {
+    Bump b{nullptr, 0};
+    SupBufs o;
+    plan_sup(b, N, M, D, N, o);
+    b.take<float>((size_t)M * D);
+    return (b.off + 255) & ~(size_t)255;
+}
+int mcrn_supports_forward(int N, int M, int D, const float* We1, const float* We2, const float* Mem, void* ws,
+                          size_t ws_bytes, float* g1, float* g2, void* stream) {
+    if (N < 1 || M < 1 || D < 1) FAIL("supports: bad sizes");
+    if (ws_bytes < mcrn_supports_workspace_bytes(N, M, D)) FAIL("workspace too small");
+    Bump b{(char*)ws, 0};
+    SupBufs o;
+    plan_sup(b, N, M, D, N, o);
+    return sup_fwd_core(N, M, D, We1, We2, Mem, o, g1, N, g2, false, (hipStream_t)stream);
+}
+int mcrn_supports_backward(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
+                           const float* dg1, const float* dg2, void* ws, size_t ws_bytes, float* dWe1, float* dWe2,
+                           float* dMem, void* stream) {
+    if (ws_bytes < mcrn_supports_workspace_bytes(N, M, D)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Bump b{(char*)ws, 0};
+    SupBufs o;
+    plan_sup(b, N, M, D, N, o);
+    // recompute g1,g2 (forward left E1,E2,L1,L2 in ws; g were caller outputs) into St1/St2 scratch
+    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, o.St1, (long long)N, N);
+    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, o.St2, (long long)N, N);
+    CK(hipMemsetAsync(dMem, 0, (size_t)M * D * sizeof(float), st));
+    return sup_bwd_core(N, M, D, We1, We2, Mem, o, o.St1, o.St2, N, dg1, dg2, N, 1, 0, dWe1, dWe2, dMem, st);
+}
+
+// ---- AGCN ---------------------------------------------------------------------------------------
+size_t mcrn_agcn_workspace_bytes(int B, int N, int C, int O, int cheb_k) {
+    if (B < 1 || N < 1 || C < 1 || O < 1 || (cheb_k != 2 && cheb_k != 3)) return 0;
+    AgcnPlan P;
+    plan_agcn(B, N, C, O, cheb_k, nullptr, P);
+    return P.total;
+}
+int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, const float* s1, const float* s2,
+                      const float* W, const float* bias, void* ws, size_t ws_bytes, float* y, void* stream) {
+    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (B < 1 || N < 1 || C < 1 || O < 1) FAIL("agcn: bad sizes");
+    if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    AgcnPlan P;
+    plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
+    const Shp& s = P.s;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    CKI(wprep(W, P.Wf, P.Wd, s, O, st));
+    CKI(bnc_to_rows(P.Z, s.Cp, 0, C, x, B, N, st));
+    CKI(zero_cols(P.Z, 0, s.Cp, s.C, s.Cp, s.R, 1, st));
+    CKI(prop_fwd(s, u, P.Z, st));
+    GemmP e = gp();
+    e.epi = EPI_BIAS; e.bias = bias; e.C[0] = P.y_rows; e.cm = plain(O); e.cn = plain(1);
+    CKI(wp_fwd(s, P.Z, P.Wf, O, e, st));
+    return rows_to_bnc(y, P.y_rows, O, 0, O, B, N, st);
+}
+int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, const float* s1, const float* s2,
+                       const float* W, void* ws, size_t ws_bytes, float* dx, float* ds1, float* ds2, float* dW,
+                       float* db, void* stream) {
+    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    AgcnPlan P;
+    plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
+    const Shp& s = P.s;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
+    CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
+    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWs, 0, (size_t)s.G * s.Cp * O * NSLAB_W * sizeof(float), st));
+    CKI(bnc_to_rows(P.dY, O, 0, O, dy, B, N, st));
+    CKI(agcn_bwd_core(s, u, P.dY, O, P.Wd, P.Z, P.dP, st));
+    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dY, O, P.dWs, st));
+    CKI(wunprep(dW, P.dWs, s, O, st));
+    CKI(colsum(P.dY, O, s.R, O, P.part, db, 0, st));
+    CKI(rows_to_bnc(dx, P.dP, s.Cp, 0, C, B, N, st));
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
+    return 0;
+}
+
+// ---- cell ---------------------------------------------------------------------------------------
+size_t mcrn_cell_workspace_bytes(int B, int N, int din, int H, int cheb_k) {
+    if (B < 1 || N < 1 || din < 0 || H < 1 || (cheb_k != 2 && cheb_k != 3)) return 0;
+    CellPlan P;
+    plan_cell(B, N, din, H, cheb_k, nullptr, P);
+    return P.total;
+}
+int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, const float* h, const float* s1,
+                      const float* s2, const float* gate_w, const float* gate_b, const float* update_w,
+                      const float* update_b, void* ws, size_t ws_bytes, float* hn, void* stream) {
+    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (B < 1 || N < 1 || din < 0 || H < 1) FAIL("cell: bad sizes");
+    if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    CellPlan P;
+    plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
+    const Shp& s = P.s;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    CKI(wprep(gate_w, P.Wf[0], P.Wd[0], s, 2 * H, st));
+    CKI(wprep(update_w, P.Wf[1], P.Wd[1], s, H, st));
+    CKI(bnc_to_rows(P.Z, s.Cp, 0, H, h, B, N, st));
+    CKI(bnc_to_rows(P.Z, s.Cp, H, din, x, B, N, st));
+    CKI(bnc_to_rows(P.Y, s.Cp, H, din, x, B, N, st));
+    CKI(zero_cols(P.Z, 0, s.Cp, s.C, s.Cp, s.R, 1, st));
+    CKI(zero_cols(P.Y, 0, s.Cp, s.C, s.Cp, s.R, 1, st));
+    CellW w{P.Wf[0], P.Wd[0], gate_b, P.Wf[1], P.Wd[1], update_b};
+    CKI(cell_fwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.hn_rows, H, st));
+    return rows_to_bnc(hn, P.hn_rows, H, 0, H, B, N, st);
+}
+int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dhn, const float* s1, const float* s2,
+                       const float* gate_w, const float* update_w, void* ws, size_t ws_bytes, float* dx, float* dh,
+                       float* ds1, float* ds2, float* dgate_w, float* dgate_b, float* dupdate_w, float* dupdate_b,
+                       void* stream) {
+    (void)gate_w; (void)update_w;
+    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    CellPlan P;
+    plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
+    const Shp& s = P.s;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
+    CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
+    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWs[0], 0, (size_t)s.G * s.Cp * 2 * H * NSLAB_W * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWs[1], 0, (size_t)s.G * s.Cp * H * NSLAB_W * sizeof(float), st));
+    CKI(bnc_to_rows(P.dacc, H, 0, H, dhn, B, N, st));
+    CellW w{P.Wf[0], P.Wd[0], nullptr, P.Wf[1], P.Wd[1], nullptr};
+    CKI(cell_bwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.dacc, P.dU, P.dG, P.dP, P.dQ, P.dacc, P.dxin, st));
+    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dG, 2 * H, P.dWs[0], st));
+    CKI(agcn_wgrad(s, P.Y, s.ZT, 1, P.dU, H, P.dWs[1], st));
+    CKI(wunprep(dgate_w, P.dWs[0], s, 2 * H, st));
+    CKI(wunprep(dupdate_w, P.dWs[1], s, H, st));
+    CKI(colsum(P.dG, 2 * H, s.R, 2 * H, P.part, dgate_b, 0, st));
+    CKI(colsum(P.dU, H, s.R, H, P.part, dupdate_b, 0, st));
+    CKI(rows_to_bnc(dh, P.dacc, H, 0, H, B, N, st));
+    if (din > 0) CKI(rows_to_bnc(dx, P.dxin, din, 0, din, B, N, st));
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
+    return 0;
+}
+
+// ---- memory head --------------------------------------------------------------------------------
+size_t mcrn_memory_workspace_bytes(int B, int N, int H, int M, int D) {
+    if (B < 1 || N < 1 || H < 1 || M < 1 || D < 1) return 0;
+    MemPlan P;
+    plan_mem(B, N, H, M, D, nullptr, P);
+    return P.total;
+}
+int mcrn_memory_forward(int B, int N, int H, int M, int D, const float* h, const float* Mem, const float* Wq,
+                        void* ws, size_t ws_bytes, float* value, float* query, float* pos, float* neg, int* ind,
+                        void* stream) {
+    if (B < 1 || N < 1 || H < 1 || M < 1 || D < 1) FAIL("memory: bad sizes");
+    if (ws_bytes < mcrn_memory_workspace_bytes(B, N, H, M, D)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    MemPlan P;
+    plan_mem(B, N, H, M, D, (char*)ws, P);
+    CKI(bnc_to_rows(P.h_rows, H, 0, H, h, B, N, st));
+    return memory_fwd_launch(P.h_rows, H, Wq, Mem, B, N, H, M, D, P.q_rows, P.att, P.ind, nullptr, 0, value, query,
+                             pos, neg, ind, st);
+}
+int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, const float* Mem, const float* Wq,
+                         const float* dvalue, const float* dquery, const float* dpos, const float* dneg, void* ws,
+                         size_t ws_bytes, float* dh, float* dMem, float* dWq, void* stream) {
+    (void)h;
+    if (ws_bytes < mcrn_memory_workspace_bytes(B, N, H, M, D)) FAIL("workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    MemPlan P;
+    plan_mem(B, N, H, M, D, (char*)ws, P);
+    const long long R = (long long)B * N;
+    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
+    CKI(memory_bwd_rows_launch(nullptr, 0, 0, dvalue, dquery, P.att, Mem, B, N, M, D, P.dval, P.dsc, P.dq, st));
+    CKI(memory_bwd_gemms(P.h_rows, H, Wq, R, H, M, D, P.att, P.q_rows, P.dval, P.dsc, P.dq, P.dh_rows, H, false,
+                         P.dWq_s, P.dMem_s, st));
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, dWq, (const float*)P.dWq_s, NSLAB_W, (long long)H * D, (long long)H * D, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dMem, (const float*)P.dMem_s, NSLAB_W, (long long)M * D, (long long)M * D, 0);
+    if (dpos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 0, dpos, B, N, D);
+    if (dneg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 1, dneg, B, N, D);
+    return rows_to_bnc(dh, P.dh_rows, H, 0, H, B, N, st);
+}
+
+// ---- optimizer tail -----------------------------------------------------------------------------
+int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                        float eps, int step, float max_norm, float grad_scale, float* scratch, float* total_norm_out,
+                        void* stream) {
+    if (!p || !g || !m || !v || !scratch || n < 1 || step < 1) FAIL("flat_clip_adam: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = cdiv(n, 256 * 8);
+    if (nblk > 1000) nblk = 1000;
+    LAUNCH(k_sumsq_stage1, dim3(nblk), dim3(256), 0, st, (const float*)g, n, grad_scale, scratch);
+    LAUNCH(k_sumsq_stage2, dim3(1), dim3(64), 0, st, (const float*)scratch, nblk, scratch + 1000);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    LAUNCH(k_clip_adam, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, max_norm,
+           grad_scale, (const float*)(scratch + 1000));
+    if (total_norm_out) CK(hipMemcpyAsync(total_norm_out, scratch + 1000, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ---- GEMM test hook -----------------------------------------------------------------------------
+int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B, float* C, float alpha,
+                  float beta, int nsplit, float* slabs, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemmP p = gp();
+    p.M = M; p.N = N; p.K = K;
+    p.A[0] = A; p.B[0] = B;
+    if (!transA) { p.am = plain(K); p.ak = plain(1); } else { p.am = plain(1); p.ak = plain(M); }
+    if (!transB) { p.bk = plain(N); p.bn = plain(1); } else { p.bk = plain(1); p.bn = plain(K); }
+    p.cm = plain(N); p.cn = plain(1);
+    p.alpha = alpha;
+    if (nsplit > 1) {
+        if (!slabs) FAIL("gemm: nsplit > 1 needs slabs");
+        CK(hipMemsetAsync(slabs, 0, (size_t)nsplit * M * N * sizeof(float), st));
+        p.C[0] = slabs; p.Cin[0] = slabs; p.beta = 1.f; p.slab = (long long)M * N;
+        CKI(gemm(p, !transA, transB != 0, nsplit, st));
+        // C = alpha*sum(slabs) (alpha already applied) + beta*C
+        if (beta == 0.f) {
+            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 0);
+        } else {
+            if (beta != 1.f) FAIL("gemm: split-K supports beta in {0,1}");
+            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 1);
+        }
+        return 0;
+    }
+    p.C[0] = C;
+    if (beta != 0.f) { p.Cin[0] = C; p.beta = beta; }
+    return gemm(p, !transA, transB != 0, 0, st);
+}
+
+}  // extern "C"

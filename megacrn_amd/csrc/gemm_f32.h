@@ -1,0 +1,314 @@
+// gemm_f32.h - exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32), wave64.
+//
+// One kernel serves every contraction of the MegaCRN hot path:
+//   C[r,c] = epi( alpha * sum_k A(r,k) * B(k,c) + beta * Cin[r,c] )
+// A, B, C are addressed through two-level strided index maps (Dim2), which is what lets the
+// node-major plane layout Z[g][n][b][c] be consumed directly as
+//   * the (N x B*Cp) right operand of the K-hop propagation  S x Z[g]
+//   * the (N*B x G*Cp) left operand of the weight-pool contraction (concat folded into K)
+//   * both operands of the N x N adjacency-gradient contraction
+// without any cat/transpose pass (reference: model/MegaCRN.py:24-27 materialises both).
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) built from 32x32
+// MFMA fragments; BK = 16.  Operands are staged through LDS with a register prefetch of the next
+// K-tile.  LDS images are conflict-free for ds_read_b32 / ds_write_b32 (stride 17 for
+// K-contiguous sources, unit stride for row-contiguous ones).
+//
+// fp32 MFMA runs at 64 FLOP/clk/SIMD (157 TF chip peak), so one ds_read_b32 per operand per
+// 64-cycle MFMA leaves the LDS and the global path far from critical; the kernel is MFMA-issue
+// bound once tiles are full.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcrn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Dim2 {          // off(i) = (i / inner) * hi + (i % inner) * lo ; inner <= 0 means plain i*lo
+    int inner;
+    long long hi;
+    long long lo;
+};
+static inline Dim2 plain(long long lo) { return Dim2{0, 0, lo}; }
+static inline Dim2 two(int inner, long long hi, long long lo) { return Dim2{inner, hi, lo}; }
+
+enum Epi { EPI_STORE = 0, EPI_GATE = 1, EPI_UPDATE = 2, EPI_BIAS = 3 };
+
+struct GemmP {
+    const float* A[2];
+    const float* B[2];
+    float* C[2];
+    const float* Cin[2];        // nullable (beta ignored then)
+    long long ak_hi[2], bk_hi[2];   // per-batch override of ak.hi / bk.hi
+    Dim2 am, ak, bk, bn, cm, cn;
+    int M, N, K;
+    int nbatch, nsplit, kchunk;     // grid.z = nbatch*nsplit ; kchunk multiple of 16
+    long long slab;                 // C/Cin offset per split
+    float alpha, beta;
+    int epi;
+    // fused GRU epilogues (model/MegaCRN.py:43-47)
+    const float* bias;
+    const float* hsrc; long long hsrc_ld;     // previous state h[r*hsrc_ld + c]
+    float* out2;       long long out2_ld;     // GATE: z*h  ; UPDATE: new state
+    const float* zr;                           // UPDATE: sigmoid gates (R x 2H)
+    int H;
+};
+
+__device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {
+    if (inner <= 0) return (long long)i * lo;
+    int q = i / inner;
+    return (long long)q * hi + (long long)(i - q * inner) * lo;
+}
+
+// ---- operand tile: E rows (m or n) x 16 k ------------------------------------------------
+// KC: memory is contiguous along k.  thread -> k = tid&15, rows (tid>>4) + 16q.
+// RC: memory is contiguous along the row index.  thread -> row = (tid&31)+32q, k = (tid>>5)+8p.
+template <int E, bool KC>
+struct Tile {
+    static constexpr int NE = E / 16;                      // elements per thread
+    static constexpr int SZ = KC ? E * 17 : 16 * E;        // LDS floats
+    long long roff[KC ? E / 16 : E / 32];
+    float reg[NE];
+
+    __device__ __forceinline__ void init_rows(int tid, int row0, int nrows, const Dim2& d) {
+        if (KC) {
+#pragma unroll
+            for (int q = 0; q < E / 16; ++q) {
+                int r = row0 + (tid >> 4) + 16 * q;
+                roff[q] = r < nrows ? d2off(d.inner, d.hi, d.lo, r) : -1;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < E / 32; ++q) {
+                int r = row0 + (tid & 31) + 32 * q;
+                roff[q] = r < nrows ? d2off(d.inner, d.hi, d.lo, r) : -1;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ base, int tid, int k0, int kend,
+                                         int kinner, long long khi, long long klo) {
+        if (KC) {
+            int k = k0 + (tid & 15);
+            bool kv = k < kend;
+            long long ko = kv ? d2off(kinner, khi, klo, k) : 0;
+#pragma unroll
+            for (int q = 0; q < E / 16; ++q)
+                reg[q] = (kv && roff[q] >= 0) ? base[roff[q] + ko] : 0.f;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                int k = k0 + (tid >> 5) + 8 * p;
+                bool kv = k < kend;
+                long long ko = kv ? d2off(kinner, khi, klo, k) : 0;
+#pragma unroll
+                for (int q = 0; q < E / 32; ++q)
+                    reg[p * (E / 32) + q] = (kv && roff[q] >= 0) ? base[roff[q] + ko] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* s, int tid) const {
+        if (KC) {
+#pragma unroll
+            for (int q = 0; q < E / 16; ++q) s[((tid >> 4) + 16 * q) * 17 + (tid & 15)] = reg[q];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < E / 32; ++q)
+                    s[((tid >> 5) + 8 * p) * E + (tid & 31) + 32 * q] = reg[p * (E / 32) + q];
+        }
+    }
+    static __device__ __forceinline__ float at(const float* s, int row, int k) {
+        return KC ? s[row * 17 + k] : s[k * E + row];
+    }
+};
+
+template <int BM, int BN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    using TA = Tile<BM, AKC>;
+    using TB = Tile<BN, BKC>;
+    __shared__ float smem[TA::SZ + TB::SZ];
+    float* sA = smem;
+    float* sB = smem + TA::SZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int z = blockIdx.z;
+    const int batch = z / p.nsplit, split = z - batch * p.nsplit;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+
+    const float* __restrict__ Ab = p.A[batch];
+    const float* __restrict__ Bb = p.B[batch];
+    const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
+
+    TA ta;
+    TB tb;
+    ta.init_rows(tid, m_blk, p.M, p.am);
+    tb.init_rows(tid, n_blk, p.N, p.bn);
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    ta.load(Ab, tid, kbeg, kend, p.ak.inner, akhi, p.ak.lo);
+    tb.load(Bb, tid, kbeg, kend, p.bk.inner, bkhi, p.bk.lo);
+    ta.store(sA, tid);
+    tb.store(sB, tid);
+    __syncthreads();
+
+    const int l31 = lane & 31, kh = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        if (more) {
+            ta.load(Ab, tid, k0 + 16, kend, p.ak.inner, akhi, p.ak.lo);
+            tb.load(Bb, tid, k0 + 16, kend, p.bk.inner, bkhi, p.bk.lo);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = TA::at(sA, wm * WM + i * 32 + l31, 2 * s + kh);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = TB::at(sB, wn * WN + j * 32 + l31, 2 * s + kh);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            ta.store(sA, tid);
+            tb.store(sB, tid);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+    float* __restrict__ Cb = p.C[batch] + (long long)split * p.slab;
+    const float* __restrict__ Cin = p.Cin[batch] ? p.Cin[batch] + (long long)split * p.slab : nullptr;
+    const int r_base = m_blk + wm * WM + 4 * kh;
+    const int c_base = n_blk + wn * WN + l31;
+#define MCRN_EPI_LOOP(BODY)                                                            \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                  \
+        const int c = c_base + j * 32;                                                 \
+        if (c < p.N) {                                                                 \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                          \
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) {                      \
+                    const int r = r_base + i * 32 + (v & 3) + 8 * (v >> 2);            \
+                    if (r < p.M) {                                                     \
+                        const float a = acc[i][j][v];                                  \
+                        BODY                                                           \
+                    }                                                                  \
+                }                                                                      \
+            }                                                                          \
+        }                                                                              \
+    }
+    if (p.epi == EPI_STORE) {
+        if (Cin) {
+            MCRN_EPI_LOOP({
+                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                Cb[off] = p.alpha * a + p.beta * Cin[off];
+            })
+        } else {
+            MCRN_EPI_LOOP({
+                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                Cb[off] = p.alpha * a;
+            })
+        }
+    } else if (p.epi == EPI_BIAS) {
+        MCRN_EPI_LOOP({
+            const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+            Cb[off] = a + p.bias[c];
+        })
+    } else if (p.epi == EPI_GATE) {
+        // z_r = sigmoid(AGCN_gate) ; candidate state input = z*h   (MegaCRN.py:43-45)
+        MCRN_EPI_LOOP({
+            const float g = 1.f / (1.f + expf(-(a + p.bias[c])));
+            Cb[(long long)r * (2 * p.H) + c] = g;
+            if (c < p.H) p.out2[(long long)r * p.out2_ld + c] = g * p.hsrc[(long long)r * p.hsrc_ld + c];
+        })
+    } else {
+        // hc = tanh(AGCN_update) ; h' = r*h + (1-r)*hc               (MegaCRN.py:46-47)
+        MCRN_EPI_LOOP({
+            const float hc = tanhf(a + p.bias[c]);
+            Cb[(long long)r * p.H + c] = hc;
+            const float rg = p.zr[(long long)r * (2 * p.H) + p.H + c];
+            const float h = p.hsrc[(long long)r * p.hsrc_ld + c];
+            p.out2[(long long)r * p.out2_ld + c] = rg * h + (1.f - rg) * hc;
+        })
+    }
+#undef MCRN_EPI_LOOP
+}
+
+// ---- host launcher ------------------------------------------------------------------------
+struct GemmStats { long long launches; double flops; };
+extern GemmStats g_gemm_stats;
+
+template <int BM, int BN>
+static inline hipError_t launch_cfg(const GemmP& p, bool akc, bool bkc, hipStream_t st) {
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
+    dim3 blk(256);
+    if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, blk, 0, st, p);
+    else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, blk, 0, st, p);
+    else if (!akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, blk, 0, st, p);
+    return hipGetLastError();
+}
+
+// Pick tile shape and split-K.  `want_split`: 0 = never split (C is a real output), otherwise the
+// maximum number of slabs the caller provisioned behind C (stride p.slab).
+static inline hipError_t launch_gemm(GemmP p, bool akc, bool bkc, int max_split, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    if (p.nbatch <= 0) p.nbatch = 1;
+    static const int cfg[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    static const double eff[4] = {1.00, 0.90, 0.90, 0.80};
+    const double slots = 256.0 * 2.0;   // CUs x resident blocks
+    int best = 3, best_split = 1;
+    double best_t = 1e300;
+    for (int i = 0; i < 4; ++i) {
+        const int bm = cfg[i][0], bn = cfg[i][1];
+        const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch;
+        int ns = 1;
+        if (max_split > 1) {
+            ns = (int)((slots + tiles - 1) / tiles);
+            if (ns > max_split) ns = max_split;
+            int maxk = p.K / 64;
+            if (maxk < 1) maxk = 1;
+            if (ns > maxk) ns = maxk;
+            if (ns < 1) ns = 1;
+        }
+        const double waves = ceil((double)tiles * ns / slots);
+        const double t = waves * (double)bm * bn * ((double)p.K / ns + 32.0) / eff[i];
+        if (t < best_t) { best_t = t; best = i; best_split = ns; }
+    }
+    int kchunk = ((p.K + best_split - 1) / best_split + 15) / 16 * 16;
+    p.nsplit = (p.K + kchunk - 1) / kchunk;
+    p.kchunk = kchunk;
+    if (max_split > 1 && p.nsplit < max_split) {
+        // unused slabs must not hold stale data: caller zero-fills or reduces only p.nsplit slabs.
+    }
+    g_gemm_stats.launches++;
+    g_gemm_stats.flops += 2.0 * p.M * p.N * (double)p.K * p.nbatch;
+    switch (best) {
+        case 0: return launch_cfg<128, 128>(p, akc, bkc, st);
+        case 1: return launch_cfg<64, 128>(p, akc, bkc, st);
+        case 2: return launch_cfg<128, 64>(p, akc, bkc, st);
+        default: return launch_cfg<64, 64>(p, akc, bkc, st);
+    }
+}
+
+}  // namespace mcrn

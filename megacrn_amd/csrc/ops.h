@@ -1,0 +1,513 @@
+// ops.h - the non-GEMM kernels of the MegaCRN hot path (gfx950, wave64).
+// Everything here is HBM/L2-bound elementwise, row-softmax or reduction work.
+// Internal activation layout is node-major: row r = n*B + b, planes Z[g][r][Cp].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcrn {
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plane-0 packing
+// ---------------------------------------------------------------------------------------------
+// dst[t][r][col0 + j] = src[b*sb + t*st + n*sn + j]   for j < w, r = n*B + b, t < T
+// (dst_t = per-step stride of the destination buffer).  Used for x / ycov input channels.
+__global__ void k_fill_cols(float* __restrict__ dst, long long dst_t, int Cp, int col0, int w,
+                            const float* __restrict__ src, long long sb, long long st, long long sn,
+                            int B, int N, int T) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)T * N * B * w;
+    if (i >= tot) return;
+    int j = (int)(i % w);
+    long long q = i / w;
+    int b = (int)(q % B); q /= B;
+    int n = (int)(q % N);
+    int t = (int)(q / N);
+    dst[t * dst_t + ((long long)n * B + b) * Cp + col0 + j] = src[b * sb + t * st + n * sn + j];
+}
+
+// dst[t][r][c] = 0 for c in [c0, c1)
+__global__ void k_zero_cols(float* __restrict__ dst, long long dst_t, int Cp, int c0, int c1,
+                            long long R, int T) {
+    int w = c1 - c0;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)T * R * w;
+    if (i >= tot) return;
+    int j = (int)(i % w);
+    long long q = i / w;
+    long long r = q % R;
+    int t = (int)(q / R);
+    dst[t * dst_t + r * Cp + c0 + j] = 0.f;
+}
+
+// batch-major (B,N,w) <-> node-major columns [col0, col0+w) of a (R x ld) buffer
+__global__ void k_bnc_to_rows(float* __restrict__ dst, long long ld, int col0, int w,
+                              const float* __restrict__ src, int B, int N) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)B * N * w;
+    if (i >= tot) return;
+    int j = (int)(i % w);
+    long long q = i / w;
+    int n = (int)(q % N);
+    int b = (int)(q / N);
+    dst[((long long)n * B + b) * ld + col0 + j] = src[i];
+}
+__global__ void k_rows_to_bnc(float* __restrict__ dst, const float* __restrict__ src, long long ld,
+                              int col0, int w, int B, int N, int accumulate) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)B * N * w;
+    if (i >= tot) return;
+    int j = (int)(i % w);
+    long long q = i / w;
+    int n = (int)(q % N);
+    int b = (int)(q / N);
+    float v = src[((long long)n * B + b) * ld + col0 + j];
+    dst[i] = accumulate ? dst[i] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AGCN weight layout:  reference rows k_global*C + c_ref  <->  internal rows (plane g, channel c')
+//   c' <  H        -> c_ref = d + c'      (state channels; the reference concatenates [x | h])
+//   c' in [H, H+d) -> c_ref = c' - H      (input channels)
+//   c' >= H+d      -> zero padding
+// plane 0 merges the two identity blocks; Wd is the d-grad variant with the Chebyshev recursion
+// folded in for cheb_k = 3 (plane0 -= W_2 blocks, k=2 planes *= 2).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_wprep(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wd,
+                        int d, int H, int Cp, int K, int O) {
+    const int G = 2 * K - 1, C = d + H;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)G * Cp * O;
+    if (i >= tot) return;
+    int o = (int)(i % O);
+    int q = (int)(i / O);
+    int cp = q % Cp, g = q / Cp;
+    float wf = 0.f, wd = 0.f;
+    if (cp < C) {
+        int cref = cp < H ? d + cp : cp - H;
+        if (g == 0) {
+            float w0 = W[((long long)(0 * K + 0) * C + cref) * O + o];
+            float w1 = W[((long long)(1 * K + 0) * C + cref) * O + o];
+            wf = w0 + w1;
+            wd = wf;
+            if (K == 3) {
+                wd -= W[((long long)(0 * K + 2) * C + cref) * O + o];
+                wd -= W[((long long)(1 * K + 2) * C + cref) * O + o];
+            }
+        } else {
+            int s = (g - 1) / (K - 1), k = 1 + (g - 1) % (K - 1);
+            wf = W[((long long)(s * K + k) * C + cref) * O + o];
+            wd = (k == 2) ? 2.f * wf : wf;
+        }
+    }
+    Wf[i] = wf;
+    Wd[i] = wd;
+}
+
+// dW (reference layout) = sum over slabs of dW' (internal layout), identity plane copied to both supports
+__global__ void k_wunprep(float* __restrict__ dW, const float* __restrict__ slabs, int nslab,
+                          long long slab, int d, int H, int Cp, int K, int O) {
+    const int C = d + H;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)2 * K * C * O;
+    if (i >= tot) return;
+    int o = (int)(i % O);
+    int q = (int)(i / O);
+    int cref = q % C, kg = q / C;
+    int s = kg / K, k = kg % K;
+    int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
+    int cp = cref < d ? H + cref : cref - d;
+    long long src = ((long long)g * Cp + cp) * O + o;
+    float v = 0.f;
+    for (int z = 0; z < nslab; ++z) v += slabs[z * slab + src];
+    dW[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjacency: g = rowsoftmax(relu(L))  (model/MegaCRN.py:171-172), one wave per row
+// ---------------------------------------------------------------------------------------------
+__global__ void k_relu_softmax_rows(const float* __restrict__ L, long long ldl, float* __restrict__ G,
+                                    long long ldg, int N) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* l = L + (long long)row * ldl;
+    float mx = 0.f;  // relu output is >= 0
+    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, l[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < N; c += 64) s += expf(fmaxf(l[c], 0.f) - mx);
+    s = wave_sum(s);
+    float inv = 1.f / s;
+    float* g = G + (long long)row * ldg;
+    for (int c = lane; c < N; c += 64) g[c] = expf(fmaxf(l[c], 0.f) - mx) * inv;
+}
+
+// dL = g * (dS - sum(dS*g)) * [L > 0], dS = sum over slabs
+__global__ void k_relu_softmax_rows_bwd(const float* __restrict__ L, long long ldl,
+                                        const float* __restrict__ G, long long ldg,
+                                        const float* __restrict__ dS, long long ldd, int nslab,
+                                        long long slab, float* __restrict__ dL, long long ldo, int N) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* g = G + (long long)row * ldg;
+    const float* l = L + (long long)row * ldl;
+    const float* d = dS + (long long)row * ldd;
+    float dot = 0.f;
+    for (int c = lane; c < N; c += 64) {
+        float v = 0.f;
+        for (int z = 0; z < nslab; ++z) v += d[z * slab + c];
+        dot += v * g[c];
+    }
+    dot = wave_sum(dot);
+    float* o = dL + (long long)row * ldo;
+    for (int c = lane; c < N; c += 64) {
+        float v = 0.f;
+        for (int z = 0; z < nslab; ++z) v += d[z * slab + c];
+        o[c] = l[c] > 0.f ? g[c] * (v - dot) : 0.f;
+    }
+}
+
+// dst[i][j] = (add ? add[i][j] : 0) + src[j][i]   (N x N, LDS-tiled 32x32 transpose)
+__global__ void k_transpose_add(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
+                                long long lds_, const float* __restrict__ add, long long lda, int N) {
+    __shared__ float t[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        int r = bx + k, c = by + tx;                     // src[r][c], r in x-tile (becomes dst column)
+        t[k][tx] = (r < N && c < N) ? src[(long long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int i = by + k, j = bx + tx;                     // dst[i][j] = src[j][i]
+        if (i < N && j < N) {
+            float v = t[tx][k];
+            if (add) v += add[(long long)i * lda + j];
+            dst[(long long)i * ldd + j] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// memory head (model/MegaCRN.py:159-166), thread per row r = n*B + b
+// LDS: Wq (H*D) | Mem (M*D) | per-thread scratch (D + M) x blockDim (thread fastest)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_memory_fwd(const float* __restrict__ h, long long ldh, const float* __restrict__ Wq,
+                             const float* __restrict__ Mem, int B, int N, int H, int M, int D,
+                             float* __restrict__ q_rows, float* __restrict__ att_rows,
+                             int* __restrict__ ind_rows,
+                             float* __restrict__ s0, long long lds0,       // decoder state [h | value] (nullable)
+                             float* __restrict__ val_bnc, float* __restrict__ q_bnc,
+                             float* __restrict__ pos_bnc, float* __restrict__ neg_bnc,
+                             int* __restrict__ ind_bnc) {
+    extern __shared__ float sm[];
+    float* sWq = sm;
+    float* sMem = sWq + H * D;
+    float* scr = sMem + M * D;
+    const int nt = blockDim.x, t = threadIdx.x;
+    for (int i = t; i < H * D; i += nt) sWq[i] = Wq[i];
+    for (int i = t; i < M * D; i += nt) sMem[i] = Mem[i];
+    __syncthreads();
+    long long R = (long long)N * B;
+    long long r = (long long)blockIdx.x * nt + t;
+    if (r >= R) return;
+    float* q = scr;              // q[d*nt + t]
+    float* sc = scr + D * nt;    // sc[m*nt + t]
+    const float* hr = h + r * ldh;
+    for (int d = 0; d < D; ++d) q[d * nt + t] = 0.f;
+    for (int c = 0; c < H; ++c) {
+        float hv = hr[c];
+        for (int d = 0; d < D; ++d) q[d * nt + t] += hv * sWq[c * D + d];
+    }
+    float mx = -3.4e38f;
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += q[d * nt + t] * sMem[m * D + d];
+        sc[m * nt + t] = s;
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int m = 0; m < M; ++m) { float e = expf(sc[m * nt + t] - mx); sc[m * nt + t] = e; den += e; }
+    float inv = 1.f / den;
+    int i0 = 0, i1 = -1; float b0 = -1.f, b1 = -1.f;
+    for (int m = 0; m < M; ++m) {
+        float a = sc[m * nt + t] * inv;
+        sc[m * nt + t] = a;
+        att_rows[r * M + m] = a;
+        if (a > b0) { b1 = b0; i1 = i0; b0 = a; i0 = m; }
+        else if (a > b1) { b1 = a; i1 = m; }
+    }
+    if (i1 < 0) i1 = i0;
+    ind_rows[r * 2] = i0; ind_rows[r * 2 + 1] = i1;
+    int n = (int)(r / B), b = (int)(r % B);
+    long long o = ((long long)b * N + n) * D;
+    if (ind_bnc) { ind_bnc[((long long)b * N + n) * 2] = i0; ind_bnc[((long long)b * N + n) * 2 + 1] = i1; }
+    for (int d = 0; d < D; ++d) {
+        float v = 0.f;
+        for (int m = 0; m < M; ++m) v += sc[m * nt + t] * sMem[m * D + d];
+        float qq = q[d * nt + t];
+        q_rows[r * D + d] = qq;
+        val_bnc[o + d] = v;
+        q_bnc[o + d] = qq;
+        pos_bnc[o + d] = sMem[i0 * D + d];
+        neg_bnc[o + d] = sMem[i1 * D + d];
+        if (s0) s0[r * lds0 + H + d] = v;
+    }
+    if (s0) for (int c = 0; c < H; ++c) s0[r * lds0 + c] = hr[c];
+}
+
+// per row: datt = dval Mem^T ; dsc = att*(datt - sum(att*datt)) ; dq = dsc Mem + dq_ext
+// dval = dval_rows[r*ldv + c0 + d] (nullable) + dval_bnc (nullable)
+__global__ void k_memory_bwd_rows(const float* __restrict__ dval_rows, long long ldv, int c0,
+                                  const float* __restrict__ dval_bnc, const float* __restrict__ dq_bnc,
+                                  const float* __restrict__ att_rows, const float* __restrict__ Mem,
+                                  int B, int N, int M, int D, float* __restrict__ dval_out,
+                                  float* __restrict__ dsc_rows, float* __restrict__ dq_rows) {
+    extern __shared__ float sm[];
+    float* sMem = sm;
+    float* scr = sMem + M * D;
+    const int nt = blockDim.x, t = threadIdx.x;
+    for (int i = t; i < M * D; i += nt) sMem[i] = Mem[i];
+    __syncthreads();
+    long long R = (long long)N * B;
+    long long r = (long long)blockIdx.x * nt + t;
+    if (r >= R) return;
+    int n = (int)(r / B), b = (int)(r % B);
+    long long o = ((long long)b * N + n) * D;
+    float* dv = scr;             // dv[d*nt+t]
+    float* da = scr + D * nt;    // da[m*nt+t]
+    for (int d = 0; d < D; ++d) {
+        float v = 0.f;
+        if (dval_rows) v += dval_rows[r * ldv + c0 + d];
+        if (dval_bnc) v += dval_bnc[o + d];
+        dv[d * nt + t] = v;
+        dval_out[r * D + d] = v;
+    }
+    float dot = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += dv[d * nt + t] * sMem[m * D + d];
+        da[m * nt + t] = s;
+        dot += s * att_rows[r * M + m];
+    }
+    for (int m = 0; m < M; ++m) {
+        float v = att_rows[r * M + m] * (da[m * nt + t] - dot);
+        da[m * nt + t] = v;
+        dsc_rows[r * M + m] = v;
+    }
+    for (int d = 0; d < D; ++d) {
+        float v = dq_bnc ? dq_bnc[o + d] : 0.f;
+        for (int m = 0; m < M; ++m) v += da[m * nt + t] * sMem[m * D + d];
+        dq_rows[r * D + d] = v;
+    }
+}
+
+// dMem[ind[r][which]] += dsel[b,n,:]   (only when the caller did not detach pos/neg)
+__global__ void k_memory_scatter(float* __restrict__ dMem, const int* __restrict__ ind_rows, int which,
+                                 const float* __restrict__ dsel_bnc, int B, int N, int D) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)N * B * D;
+    if (i >= tot) return;
+    int d = (int)(i % D);
+    long long r = i / D;
+    int n = (int)(r / B), b = (int)(r % B);
+    atomicAdd(&dMem[(long long)ind_rows[r * 2 + which] * D + d], dsel_bnc[((long long)b * N + n) * D + d]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder projection (model/MegaCRN.py:186-191): one wave per row, lanes over channels
+// go = h' Wp^T + bp -> out[b,t,n,:] ; next step's `go` input channels (teacher forcing folded in)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_proj_fwd(const float* __restrict__ hn, long long ldh, const float* __restrict__ Wp,
+                           const float* __restrict__ bp, int Hd, int od, int B, int N,
+                           float* __restrict__ out_bt, long long out_sb, long long out_sn,   // out[b*sb + n*sn + j]
+                           float* __restrict__ nextZ, float* __restrict__ nextY, long long ldn, int col0,
+                           const float* __restrict__ lab_bt /* labels[:,t] or null */) {
+    long long R = (long long)N * B;
+    int wpb = blockDim.x >> 6;
+    int lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += (long long)gridDim.x * wpb) {
+        int n = (int)(r / B), b = (int)(r % B);
+        for (int j = 0; j < od; ++j) {
+            float s = 0.f;
+            for (int c = lane; c < Hd; c += 64) s += hn[r * ldh + c] * Wp[(long long)j * Hd + c];
+            s = wave_sum(s);
+            if (lane == 0) {
+                float go = s + bp[j];
+                long long o = b * out_sb + n * out_sn + j;
+                out_bt[o] = go;
+                if (nextZ) {
+                    float nx = lab_bt ? lab_bt[o] : go;
+                    nextZ[r * ldn + col0 + j] = nx;
+                    nextY[r * ldn + col0 + j] = nx;
+                }
+            }
+        }
+    }
+}
+
+// dgo[r][j] = d_out[b,t,n,j] + (use_next ? dxin[r][j] : 0) ; dhn[r][c] = dstate[r][c] + sum_j dgo*Wp[j][c]
+__global__ void k_proj_bwd(const float* __restrict__ dout_bt, long long out_sb, long long out_sn,
+                           const float* __restrict__ dxin, long long ldx, int use_next,
+                           const float* __restrict__ Wp, int Hd, int od, int B, int N,
+                           const float* __restrict__ dstate, float* __restrict__ dhn,
+                           float* __restrict__ dgo_rows) {
+    long long R = (long long)N * B;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * Hd) return;
+    int c = (int)(i % Hd);
+    long long r = i / Hd;
+    int n = (int)(r / B), b = (int)(r % B);
+    float acc = dstate ? dstate[i] : 0.f;
+    for (int j = 0; j < od; ++j) {
+        float g = dout_bt[b * out_sb + n * out_sn + j];
+        if (use_next) g += dxin[r * ldx + j];
+        acc += g * Wp[(long long)j * Hd + c];
+        if (c == 0) dgo_rows[r * od + j] = g;
+    }
+    dhn[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU backward elementwise (SURVEY.md A.3 "cell")
+// ---------------------------------------------------------------------------------------------
+// A: dr, dhc from dh' ; dU = dhc*(1-hc^2) ; dG[:,H:] = dr*r*(1-r) ; dacc = dh'*r
+__global__ void k_cell_bwd_a(const float* __restrict__ dhn, const float* __restrict__ z0, long long ldz,
+                             const float* __restrict__ zr, const float* __restrict__ hc, int H, long long R,
+                             float* __restrict__ dU, float* __restrict__ dG, float* __restrict__ dacc) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * H) return;
+    int c = (int)(i % H);
+    long long r = i / H;
+    float g = dhn[i];
+    float h = z0[r * ldz + c];
+    float rr = zr[r * 2 * H + H + c];
+    float hv = hc[i];
+    dU[i] = g * (1.f - rr) * (1.f - hv * hv);
+    dG[r * 2 * H + H + c] = g * (h - hv) * rr * (1.f - rr);
+    dacc[i] = g * rr;
+}
+// B: dzh = dY0[state part] ; dG[:, :H] = dzh*h*z*(1-z) ; dacc += dzh*z
+__global__ void k_cell_bwd_b(const float* __restrict__ dy0, long long ldy, const float* __restrict__ z0,
+                             long long ldz, const float* __restrict__ zr, int H, long long R,
+                             float* __restrict__ dG, float* __restrict__ dacc) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * H) return;
+    int c = (int)(i % H);
+    long long r = i / H;
+    float dzh = dy0[r * ldy + c];
+    float h = z0[r * ldz + c];
+    float z = zr[r * 2 * H + c];
+    dG[r * 2 * H + c] = dzh * h * z * (1.f - z);
+    dacc[i] += dzh * z;
+}
+// C: dh_prev = dacc + dZ0[state] ; dxin = dY0[input] + dZ0[input]
+__global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dy0, long long ld,
+                             int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int C = H + d;
+    if (i >= R * C) return;
+    int c = (int)(i % C);
+    long long r = i / C;
+    if (c < H) dacc[r * H + c] += dz0[r * ld + c];
+    else dxin[r * d + (c - H)] = dz0[r * ld + c] + dy0[r * ld + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic column sums:  out[c] (+)= sum_r w[r]*X[r*ld + c]   (w nullable), two stages
+// ---------------------------------------------------------------------------------------------
+__global__ void k_colsum_stage1(const float* __restrict__ X, long long ld, long long rows, int C,
+                                int chunk, float* __restrict__ part) {
+    long long r0 = (long long)blockIdx.x * chunk;
+    long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += X[r * ld + c];
+        part[(long long)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void k_colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ out,
+                                int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[i] = sum_z slabs[z*slab + i]
+__global__ void k_reduce_slabs(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
+                               long long slab, long long n, int accumulate) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slabs[z * slab + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// strided 2-D copy:  dst[r*ldd + c] = src[r*lds + c]
+__global__ void k_copy2d(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
+                         long long lds_, long long rows, int cols) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    int c = (int)(i % cols);
+    long long r = i / cols;
+    dst[r * ldd + c] = src[r * lds_ + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat clip_grad_norm_ + Adam   (model/traintest_MegaCRN.py:104,129-130)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sumsq_stage1(const float* __restrict__ g, long long n, float scale, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = g[i] * scale;
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void k_sumsq_stage2(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    // single wave; deterministic order
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = sqrtf(s);
+}
+__global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt, float max_norm, float scale,
+                            const float* __restrict__ total_norm) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float tn = total_norm[0];
+    float coef = fminf(1.f, max_norm / (tn + 1e-6f));
+    float gi = g[i] * scale * coef;
+    g[i] = gi;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace mcrn

@@ -1,0 +1,259 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the oracle and the committed golden vectors.
+
+Tolerance: north_star asks for <= 1e-4 relative fp32 against the reference CPU path; `relerr` is
+max|a-b| / max|b| per tensor.  Truth for gradients is the oracle in float64 on the same inputs (the
+oracle itself is pinned to the reference in tests/test_oracle_golden.py).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_case, relerr, SC_MEAN, SC_STD
+from oracle import megacrn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import megacrn_amd
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return megacrn_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM hook
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,tA,tB,ns", [
+    (64, 64, 16, 0, 0, 1), (33, 17, 5, 0, 0, 1), (207, 4160, 207, 0, 0, 1), (130, 70, 300, 1, 0, 1),
+    (100, 90, 77, 0, 1, 1), (65, 129, 1000, 1, 1, 1), (207, 207, 8320, 0, 1, 16), (340, 128, 13248, 1, 0, 64),
+    (1, 128, 5000, 1, 0, 8), (256, 256, 256, 0, 0, 1),
+])
+def test_gemm(amd, M, N, K, tA, tB, ns):
+    from megacrn_amd._lib import lib, check
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = 0.5 * ((A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64))
+    beta = 1.0 if ns > 1 else -2.0
+    ref = ref + beta * C0
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    slabs = torch.empty(max(ns, 1) * M * N, device="cuda") if ns > 1 else None
+    check(lib.mcrn_gemm_f32(M, N, K, tA, tB, dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), 0.5, beta, ns,
+                            None if slabs is None else slabs.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "gemm")
+    torch.cuda.synchronize()
+    assert relerr(dC.cpu().numpy(), ref) < 2e-6 * max(1, np.sqrt(K) / 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone ops vs reference goldens
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_agcn_golden(amd, golden_dir, tag):
+    z = np.load(f"{golden_dir}/ops_f64.npz")
+    g = lambda k: z[f"agcn_{tag}:{k}"]
+    B, N, Cc, Oo, K = [int(v) for v in g("meta")]
+    m = amd.AGCN(Cc, Oo, K).cuda()
+    with torch.no_grad():
+        m.weights.copy_(dev(g("w"))); m.bias.copy_(dev(g("b")))
+    x, s1, s2 = (dev(g(k)).requires_grad_() for k in ("x", "s1", "s2"))
+    y = m(x, [s1, s2])
+    y.backward(dev(g("dy")))
+    torch.cuda.synchronize()
+    assert relerr(y.detach().cpu().numpy(), g("y")) < TOL
+    for got, want in ((x.grad, "dx"), (s1.grad, "ds1"), (s2.grad, "ds2"), (m.weights.grad, "dw"), (m.bias.grad, "db")):
+        assert relerr(got.cpu().numpy(), g(want)) < TOL, want
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cell_golden(amd, golden_dir, tag):
+    z = np.load(f"{golden_dir}/ops_f64.npz")
+    g = lambda k: z[f"cell_{tag}:{k}"]
+    B, N, din, H, K = [int(v) for v in g("meta")]
+    c = amd.AGCRNCell(N, din, H, K).cuda()
+    with torch.no_grad():
+        c.gate.weights.copy_(dev(g("gw"))); c.gate.bias.copy_(dev(g("gb")))
+        c.update.weights.copy_(dev(g("uw"))); c.update.bias.copy_(dev(g("ub")))
+    x, h, s1, s2 = (dev(g(k)).requires_grad_() for k in ("x", "h", "s1", "s2"))
+    hn = c(x, h, [s1, s2])
+    hn.backward(dev(g("dhn")))
+    torch.cuda.synchronize()
+    assert relerr(hn.detach().cpu().numpy(), g("hn")) < TOL
+    for got, want in ((x.grad, "dx"), (h.grad, "dh"), (s1.grad, "ds1"), (s2.grad, "ds2"),
+                      (c.gate.weights.grad, "dgw"), (c.gate.bias.grad, "dgb"),
+                      (c.update.weights.grad, "duw"), (c.update.bias.grad, "dub")):
+        assert relerr(got.cpu().numpy(), g(want)) < TOL, want
+
+
+def test_supports_and_memory_vs_oracle(amd):
+    from megacrn_amd.modules import _SupportsFn, _MemoryFn
+    rng = np.random.default_rng(5)
+    N, M, D, H, B = 45, 7, 12, 10, 3
+    We1, We2, Mem, Wq = (rng.standard_normal(s) * 0.5 for s in ((N, M), (N, M), (M, D), (H, D)))
+    g1, g2, cs = O.supports_fwd(We1, We2, Mem)
+    dg1, dg2 = rng.standard_normal((N, N)), rng.standard_normal((N, N))
+    rW1, rW2, rM = O.supports_bwd(dg1, dg2, cs)
+    tW1, tW2, tM = (dev(a).requires_grad_() for a in (We1, We2, Mem))
+    a, b = _SupportsFn.apply(tW1, tW2, tM)
+    (a * dev(dg1)).sum().add((b * dev(dg2)).sum()).backward()
+    torch.cuda.synchronize()
+    assert relerr(a.detach().cpu().numpy(), g1) < TOL and relerr(b.detach().cpu().numpy(), g2) < TOL
+    for got, want in ((tW1.grad, rW1), (tW2.grad, rW2), (tM.grad, rM)):
+        assert relerr(got.cpu().numpy(), want) < TOL
+    # memory head, including non-detached pos/neg
+    h = rng.standard_normal((B, N, H))
+    val, q, pos, neg, cm = O.memory_fwd(h, Mem, Wq)
+    dv, dq, dp, dn = (rng.standard_normal((B, N, D)) for _ in range(4))
+    rdh, rdM, rdWq = O.memory_bwd(dv, dq, dp, dn, cm)
+    th, tM, tWq = (dev(a).requires_grad_() for a in (h, Mem, Wq))
+    v_, q_, p_, n_, ind = _MemoryFn.apply(th, tM, tWq)
+    ((v_ * dev(dv)).sum() + (q_ * dev(dq)).sum() + (p_ * dev(dp)).sum() + (n_ * dev(dn)).sum()).backward()
+    torch.cuda.synchronize()
+    for got, want in ((v_, val), (q_, q), (p_, pos), (n_, neg)):
+        assert relerr(got.detach().cpu().numpy(), want) < TOL
+    assert (ind.cpu().numpy() == cm[5]).all()
+    for got, want in ((th.grad, rdh), (tM.grad, rdM), (tWq.grad, rdWq)):
+        assert relerr(got.cpu().numpy(), want) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model vs goldens (reference outputs) and the float64 oracle
+# ------------------------------------------------------------------------------------------------
+def build(amd, P, m):
+    model = amd.MegaCRN(num_nodes=m["N"], input_dim=1, output_dim=1, horizon=m["T_out"], rnn_units=m["H"],
+                        num_layers=m["num_layers"], cheb_k=m["cheb_k"], mem_num=m["M"], mem_dim=m["D"],
+                        cl_decay_steps=m["cl_decay"])
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in P.items()})
+    return model.cuda()
+
+
+CASES = ["tiny", "odd", "cheb2", "layers2", "metrla"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_model_eval_forward(amd, name):
+    rec, P, m = load_case(name, "f32")
+    model = build(amd, P, m).eval()
+    with torch.no_grad():
+        outs = model(dev(rec["x"]), dev(rec["ycov"]))
+    torch.cuda.synchronize()
+    for nm, o in zip(("output", "h_att", "query", "pos", "neg"), outs):
+        assert relerr(o.cpu().numpy(), rec["eval:" + nm]) < TOL, nm
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_model_train_step(amd, name):
+    rec, P, m = load_case(name, "f32")
+    model = build(amd, P, m).train()
+    teacher = [bool(v) for v in rec["teacher"]]
+    model._teacher_flags = lambda labels, bs: teacher
+    x, ycov, y = dev(rec["x"]), dev(rec["ycov"]), dev(rec["labels"])
+    outs = model(x, ycov, y, int(rec["batches_seen"]))
+    output, h_att, query, pos, neg = outs
+    # trainer loss (model/traintest_MegaCRN.py:118-125) with torch ops on device
+    y_pred, y_true = output * SC_STD + SC_MEAN, y * SC_STD + SC_MEAN
+    mask = (y_true != 0).float(); mask = mask / mask.mean()
+    l1 = (torch.abs(y_pred - y_true) * mask).mean()
+    l2 = torch.nn.TripletMarginLoss(margin=1.0)(query, pos.detach(), neg.detach())
+    l3 = torch.nn.MSELoss()(query, pos.detach())
+    loss = l1 + 0.01 * l2 + 0.01 * l3
+    loss.backward()
+    torch.cuda.synchronize()
+    for nm, o in zip(("output", "h_att", "query", "pos", "neg"), outs):
+        assert relerr(o.detach().cpu().numpy(), rec["train:" + nm]) < TOL, nm
+    assert abs(loss.item() - rec["train:loss"][0]) / rec["train:loss"][0] < TOL
+    # float64 oracle gradients on the same inputs
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    o64, cache = O.model_fwd(P64, rec["x"].astype(np.float64), rec["ycov"].astype(np.float64),
+                             rec["labels"].astype(np.float64), teacher, cheb_k=m["cheb_k"], num_layers=m["num_layers"])
+    # loss gradient in fp32 like the trainer: the `y_true != 0` mask relies on standardized zeros
+    # round-tripping to exact 0 in fp32; in float64 they would not
+    _, d_out, d_q = O.loss_fwd_bwd(tuple(o.astype(np.float32) for o in o64), rec["labels"], SC_MEAN, SC_STD)
+    G, _ = O.model_bwd(d_out.astype(np.float64), cache, d_query=d_q.astype(np.float64))
+    worst = {}
+    for k, p in model.named_parameters():
+        worst[k] = relerr(p.grad.cpu().numpy(), G[k])
+        # the reference's own fp32 gradients are a second, looser witness
+        assert relerr(p.grad.cpu().numpy(), rec["g:" + k]) < 5e-4, ("golden", k)
+    assert max(worst.values()) < TOL, worst
+
+
+def test_model_non_detached_pos_neg(amd):
+    """Gradient through pos/neg (the module surface does not detach; only the trainer does)."""
+    rec, P, m = load_case("tiny", "f64")
+    model = build(amd, P, m).eval()
+    x, ycov = dev(rec["x"]), dev(rec["ycov"])
+    outs = model(x, ycov)
+    rng = np.random.default_rng(0)
+    ws = [rng.standard_normal(o.shape) for o in outs]
+    sum((o * dev(w)).sum() for o, w in zip(outs, ws)).backward()
+    torch.cuda.synchronize()
+    o64, cache = O.model_fwd(P, rec["x"], rec["ycov"], cheb_k=m["cheb_k"])
+    G, _ = O.model_bwd(ws[0], cache, d_hatt=ws[1], d_query=ws[2], d_pos=ws[3], d_neg=ws[4])
+    for k, p in model.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), G[k]) < TOL, k
+
+
+def test_full_size_metrla_vs_oracle(amd):
+    """BASELINE configs[1] shape (N=207, B=64, T=12, H=64): forward vs the float32 oracle, plus
+    size-independent properties: batch-permutation equivariance and workspace reuse determinism."""
+    B, N, T, H = 64, 207, 12, 64
+    P = O.init_params(N, rnn_units=H, seed=3)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=3, M=20, D=64, cl_decay=2000)
+    model = build(amd, P, m).eval()
+    with torch.no_grad():
+        o1 = model(dev(x), dev(ycov))
+        o2 = model(dev(x), dev(ycov))
+        perm = rng.permutation(B)
+        o3 = model(dev(x[perm]), dev(ycov[perm]))
+    torch.cuda.synchronize()
+    ref, _ = O.model_fwd(P, x, ycov)
+    for a, b in zip(o1, ref):
+        assert relerr(a.cpu().numpy(), b) < TOL
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b), "same inputs, same workspace -> bit-identical"
+    for a, b in zip(o1, o3):
+        assert relerr(b.cpu().numpy(), a.cpu().numpy()[perm]) < 1e-5
+
+
+def test_flat_clip_adam(amd):
+    from megacrn_amd._lib import lib, check
+    rng = np.random.default_rng(1)
+    n = 388761
+    p, g = rng.standard_normal(n).astype(np.float32), (rng.standard_normal(n) * 0.3).astype(np.float32)
+    P = {"w": p.astype(np.float64).copy()}
+    G = {"w": (g.astype(np.float64) * 0.5)}
+    opt = O.Adam(P, lr=0.01, eps=1e-3)
+    tp, tg = dev(p), dev(g)
+    tm, tv = torch.zeros_like(tp), torch.zeros_like(tp)
+    scratch, tn = torch.empty(2048, device="cuda"), torch.empty(1, device="cuda")
+    for step in (1, 2, 3):
+        G = {"w": g.astype(np.float64) * 0.5}
+        gn = O.clip_grad_norm(G, 5.0)
+        opt.step(P, G)
+        tg.copy_(dev(g))
+        check(lib.mcrn_flat_clip_adam(tp.data_ptr(), tg.data_ptr(), tm.data_ptr(), tv.data_ptr(), n, 0.01, 0.9, 0.999,
+                                      1e-3, step, 5.0, 0.5, scratch.data_ptr(), tn.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "adam")
+        torch.cuda.synchronize()
+        assert abs(tn.item() - gn) / gn < 1e-5
+        assert relerr(tp.cpu().numpy(), P["w"]) < 1e-5
+
+
+def test_errors_are_loud(amd):
+    with pytest.raises((ValueError, RuntimeError)):
+        amd.AGCN(4, 4, 4).cuda()(torch.randn(2, 5, 4, device="cuda"), [torch.eye(5, device="cuda")] * 2)
+    with pytest.raises(RuntimeError):
+        amd.MegaCRN(5, 1, 1, 2, 4)(torch.randn(1, 2, 5, 1), torch.randn(1, 2, 5, 1))
