@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - training samples/sec of the MegaCRN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference trainer's optimizer step (model/traintest_MegaCRN.py:115-130): forward,
+3-term loss, backward, one all-reduce of the flat gradient bucket (N>1), clip_grad_norm_(5), Adam.
+Inputs are synthetic and already resident in HBM when the timed region starts.
+Weak scaling: every rank processes a full config batch.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "metrla":  dict(N=207, B=64, T=12, H=64, M=20, D=64, label="METR-LA-shaped"),
+    "pemsbay": dict(N=325, B=64, T=12, H=64, M=20, D=64, label="PEMS-BAY-shaped"),
+    "expytky": dict(N=1843, B=32, T=6, H=32, M=10, D=32, label="EXPY-TKY-shaped"),
+    "syn8192": dict(N=8192, B=32, T=12, H=64, M=20, D=64, label="synthetic N=8192"),
+}
+SC_MEAN, SC_STD = 54.4, 19.5
+PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
+
+
+def synth(cfg, B, seed, device):
+    """x, labels ~ N(0,1) with 8% standardized zeros; ycov = time-of-day ramp."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    N, T = cfg["N"], cfg["T"]
+    miss = (0.0 - SC_MEAN) / SC_STD
+    x = torch.randn(B, T, N, 1, generator=g)
+    y = torch.randn(B, T, N, 1, generator=g)
+    x[torch.rand(x.shape, generator=g) < 0.08] = miss
+    y[torch.rand(y.shape, generator=g) < 0.08] = miss
+    t0 = torch.randint(0, 288, (B, 1, 1, 1), generator=g).float()
+    ycov = ((t0 + T + torch.arange(T).view(1, T, 1, 1)) / 288.0) % 1.0
+    ycov = ycov.expand(B, T, N, 1).contiguous()
+    return x.to(device), ycov.to(device), y.to(device)
+
+
+def alg_flops_forward(cfg, B):
+    """Algorithmic FLOPs of one forward (BASELINE.md section 4 / SURVEY.md 8(d)); train step = 3x."""
+    N, T, H, M, D, K = cfg["N"], cfg["T"], cfg["H"], cfg["M"], cfg["D"], 3
+    Hd = H + D
+
+    def agcn(Cc, O):
+        return 2 * (K - 1) * 2 * N * N * B * Cc + 2 * B * N * (2 * K * Cc) * O
+
+    f = T * (agcn(1 + H, 2 * H) + agcn(1 + H, H)) + T * (agcn(2 + Hd, 2 * Hd) + agcn(2 + Hd, Hd))
+    f += 2 * (2 * N * M * D) + 2 * (2 * N * N * D) + 2 * B * N * H * D + 4 * B * N * D * M + T * 2 * B * N * Hd
+    return float(f)
+
+
+def cpu_baseline(cfg, sample_B, steps):
+    """The numpy oracle (a port of the reference CPU path) timed on this host, bounded sample."""
+    from oracle import megacrn_oracle as O
+    N, T, H = cfg["N"], cfg["T"], cfg["H"]
+    P = O.init_params(N, rnn_units=H, mem_num=cfg["M"], mem_dim=cfg["D"], seed=0)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
+    yc = rng.random((sample_B, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
+    opt = O.Adam(P)
+    O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
+    t = time.perf_counter()
+    for s in range(steps):
+        O.train_step(P, opt, x, yc, y, [s % 2 == 0] * T, SC_MEAN, SC_STD)
+    dt = time.perf_counter() - t
+    return sample_B * steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="metrla", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import megacrn_amd
+    from megacrn_amd import dp
+    from megacrn_amd._lib import lib, check
+    from megacrn_amd.trainer import FlatTrainer
+    import torch.distributed as dist
+
+    rank, local_rank, world = dp.init_from_env("nccl")
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["B"]
+
+    torch.manual_seed(1234)            # identical init on every rank (also broadcast by the trainer)
+    dp.seed_curriculum(1234)           # shared numpy stream: same teacher-forcing draws on all ranks
+    model = megacrn_amd.MegaCRN(num_nodes=cfg["N"], input_dim=1, output_dim=1, horizon=cfg["T"],
+                                rnn_units=cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(device).train()
+    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+    x, ycov, y = synth(cfg, B, 1234 + rank, device)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = tr.train_step(x, ycov, y)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(x, ycov, y)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+    launches = lib.mcrn_last_launch_count()
+
+    # ---- roofline leg: HIP events around every launch of one GEMM role during real train steps
+    roles, roof = {}, None
+    if not args.no_roofline:
+        for role in range(1, 7):
+            check(lib.mcrn_prof_begin(role), "prof_begin")
+            tr.train_step(x, ycov, y)
+            ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+            torch.cuda.synchronize()
+            check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
+            roles[ROLE_NAMES[role]] = dict(ms_per_step=round(ms.value, 4), launches_per_step=n.value,
+                                           avg_us=round(1e3 * ms.value / max(n.value, 1), 3),
+                                           alg_tflops=round(af.value / (ms.value * 1e-3) / 1e12, 2) if ms.value else 0,
+                                           exec_tflops=round(ef.value / (ms.value * 1e-3) / 1e12, 2) if ms.value else 0)
+        sync_all()
+        # dominant kernel of the path = forward K-hop propagation (north_star): average over several steps
+        check(lib.mcrn_prof_begin(1), "prof_begin")
+        nrep = 5
+        for _ in range(nrep):
+            tr.train_step(x, ycov, y)
+        ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        torch.cuda.synchronize()
+        check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
+        ach = af.value / (ms.value * 1e-3)
+        roof = {"bound": "mfma", "kernel": "mcrn::gemm_f32_kernel<..., ROLE=1> (K-hop propagation S x Z)",
+                "achieved": round(ach / 1e12, 3), "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+                "avg_launch_us": round(1e3 * ms.value / n.value, 3), "launches": n.value,
+                "alg_flops_per_launch": af.value / n.value}
+        sync_all()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample_B = max(1, B // 8)
+        v, secs = cpu_baseline(cfg, sample_B, 4)
+        cpu = {"value": round(v, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"oracle/megacrn_oracle.py (numpy, BLAS threads={os.cpu_count()}) full train step on "
+                         f"{sample_B} of the {B} samples of the same {cfg['label']} workload, 4 timed steps "
+                         f"after 1 warm-up ({secs:.1f} s)"}
+
+    if rank == 0:
+        gb = B * world
+        val = gb * args.steps / dt
+        step_flops = 3.0 * alg_flops_forward(cfg, B)
+        out = {
+            "metric": "training samples/sec (12-step seq2seq)" if cfg["T"] == 12 else "training samples/sec (6-step seq2seq)",
+            "value": round(val, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} "
+                                   f"mem={cfg['M']}x{cfg['D']} cheb_k=3, per-GPU batch {B}, full train step "
+                                   f"(fwd + 3-term loss + bwd + all-reduce + clip + Adam)",
+                       "global_batch": gb, "parallelism": f"dp{world}"},
+            "step_alg_tflops": round(step_flops * world / (dt / args.steps) / 1e12, 2),
+            "kernel_launches_per_step": launches, "final_loss": round(final_loss, 5),
+        }
+        if roof:
+            out["roofline"] = roof
+            out["gemm_roles"] = roles
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,8 +150,19 @@ int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, flo
 int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B,
                   float* C, float alpha, float beta, int nsplit, float* slabs, void* stream);
 
-/* name and total launches of the last model forward+backward (for bench/roofline bookkeeping) */
+/* kernel launches issued since the last mcrn_model_forward began (bench bookkeeping) */
 int mcrn_last_launch_count(void);
+
+/* ---- live kernel timing for bench.py's roofline leg ----
+ * Between mcrn_prof_begin(role) and mcrn_prof_end(), every launch of the GEMM role `role` is
+ * bracketed by hipEventRecord on the stream it is launched on.  Roles (= last template argument
+ * of mcrn::gemm_f32_kernel in rocprofv3 output): 1 propagation S x Z (model/MegaCRN.py:25),
+ * 2 weight pool + GRU epilogue (:27,:43-47), 3 d-grad, 4 S^T propagation (backward),
+ * 5 adjacency gradient, 6 weight gradient, 0 everything else.
+ * mcrn_prof_end synchronises on the recorded events and returns the summed kernel time, the number
+ * of launches, their algorithmic flops (true channel counts) and executed flops. */
+int mcrn_prof_begin(int role);
+int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);
 
 #ifdef __cplusplus
 }

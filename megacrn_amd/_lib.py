@@ -18,7 +18,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_gemm_f32",
+    "mcrn_flat_clip_adam", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end",
 ]
 
 
@@ -96,6 +96,11 @@ def _load():
     lib.mcrn_flat_clip_adam.argtypes = [vp, vp, vp, vp, ll, f, f, f, f, i, f, f, vp, vp, vp]
     lib.mcrn_gemm_f32.restype = i
     lib.mcrn_gemm_f32.argtypes = [i, i, i, i, i, vp, vp, vp, f, f, i, vp, vp]
+    lib.mcrn_prof_begin.restype = i
+    lib.mcrn_prof_begin.argtypes = [i]
+    lib.mcrn_prof_end.restype = i
+    lib.mcrn_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]
     return lib
 
 

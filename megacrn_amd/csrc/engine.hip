@@ -51,14 +51,34 @@ static int g_launches = 0;
         CK(hipGetLastError());                                                                \
     } while (0)
 
-static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, hipStream_t st) {
+// ---- live profiler: HIP events around every launch of one role (bench.py roofline leg) ---------
+struct Prof {
+    int role = -1;
+    int n = 0;
+    double alg_flops = 0, exec_flops = 0;
+    static const int MAXEV = 8192;
+    hipEvent_t ev[2 * MAXEV];
+    bool created = false;
+};
+static Prof g_prof;
+
+static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
     if (!p.nbatch) p.nbatch = 1;
     for (int b = 0; b < 2; ++b) {   // per-batch hi strides default to the Dim2 value
         if (!p.ak_hi[b]) p.ak_hi[b] = p.ak.hi;
         if (!p.bk_hi[b]) p.bk_hi[b] = p.bk.hi;
     }
     ++g_launches;
-    CK(launch_gemm(p, akc, bkc, max_split, st));
+    const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
+    if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    CK(launch_gemm(p, akc, bkc, max_split, role, st));
+    if (prof) {
+        CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+        const double ex = 2.0 * p.M * p.N * (double)p.K * p.nbatch;
+        g_prof.exec_flops += ex;
+        g_prof.alg_flops += p.alg_flops > 0 ? p.alg_flops : ex;
+        ++g_prof.n;
+    }
     return 0;
 }
 
@@ -126,7 +146,9 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
         p.C[b] = Z + (1 + b * (s.K - 1)) * s.PS;
         p.Cin[b] = nullptr;
     }
-    CKI(gemm(p, true, false, 0, st));
+    // algorithmic flops per launch: 2 supports x 2*N^2*B*C with the TRUE channel count (no pad)
+    p.alg_flops = 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
+    CKI(gemm(p, true, false, 0, ROLE_PROP, st));
     if (s.K == 3) {   // x2 = 2 S x1 - x0
         for (int b = 0; b < 2; ++b) {
             p.B[b] = Z + (1 + 2 * b) * s.PS;
@@ -134,7 +156,7 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
             p.Cin[b] = Z;
         }
         p.alpha = 2.f; p.beta = -1.f;
-        CKI(gemm(p, true, false, 0, st));
+        CKI(gemm(p, true, false, 0, ROLE_PROP, st));
     }
     return 0;
 }
@@ -146,7 +168,8 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
     p.A[0] = Z; p.B[0] = Wf;
     p.am = plain(s.Cp); p.ak = two(s.Cp, s.PS, 1); p.ak_hi[0] = s.PS;
     p.bk = plain(O); p.bn = plain(1);
-    return gemm(p, true, false, 0, st);
+    p.alg_flops = 2.0 * (double)s.R * (2.0 * s.K * s.C) * O;   // reference K = 2*cheb_k*C
+    return gemm(p, true, false, 0, ROLE_WP, st);
 }
 
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
@@ -158,7 +181,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.A[0] = dY; p.am = plain(O); p.ak = plain(1);
         p.B[0] = Wd; p.bk = plain(1); p.bn = plain(O);
         p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
-        CKI(gemm(p, true, true, 0, st));
+        CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
     }
     if (s.K == 3) {   // d1 += S^T e2     (e2 = 2 d2, folded into Wd)
         GemmP p = gp();
@@ -173,7 +196,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             p.C[b] = dP + (1 + 2 * b) * s.PS;
             p.Cin[b] = p.C[b];
         }
-        CKI(gemm(p, true, false, 0, st));
+        CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
     {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
         GemmP p = gp();
@@ -190,7 +213,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             p.C[b] = u.dS + (long long)b * u.nslab * u.slab;
             p.Cin[b] = p.C[b];
         }
-        CKI(gemm(p, true, true, u.nslab, st));
+        CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
     }
     {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b
         GemmP p = gp();
@@ -201,7 +224,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.bn = plain(1);
         p.C[0] = dP; p.Cin[0] = dP; p.cm = plain(s.ld); p.cn = plain(1);
         p.beta = 1.f;
-        CKI(gemm(p, true, false, 0, st));
+        CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
     return 0;
 }
@@ -216,7 +239,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
     p.B[0] = dYall; p.bk = plain(O); p.bn = plain(1);
     p.C[0] = slabs; p.Cin[0] = slabs; p.cm = plain(O); p.cn = plain(1);
     p.beta = 1.f; p.slab = (long long)s.G * s.Cp * O;
-    return gemm(p, false, false, NSLAB_W, st);
+    return gemm(p, false, false, NSLAB_W, ROLE_WGRAD, st);
 }
 
 static int colsum(const float* X, long long ld, long long rows, int C, float* part, float* out,
@@ -285,7 +308,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.A[0] = i ? We2 : We1; p.am = plain(M); p.ak = plain(1);
         p.B[0] = Mem; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = i ? o.E2 : o.E1; p.cm = plain(D); p.cn = plain(1);
-        CKI(gemm(p, true, false, 0, st));
+        CKI(gemm(p, true, false, 0, ROLE_MISC, st));
     }
     {   // L1 = E1 E2^T
         GemmP p = gp();
@@ -293,7 +316,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.A[0] = o.E1; p.am = plain(D); p.ak = plain(1);
         p.B[0] = o.E2; p.bk = plain(1); p.bn = plain(D);
         p.C[0] = o.L1; p.cm = plain(o.ldS); p.cn = plain(1);
-        CKI(gemm(p, true, true, 0, st));
+        CKI(gemm(p, true, true, 0, ROLE_MISC, st));
     }
     CKI(transpose(o.L2, o.ldS, o.L1, o.ldS, nullptr, 0, N, st));
     LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, N);
@@ -318,7 +341,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.A[0] = o.dLs; p.am = plain(o.ldS); p.ak = plain(1);
         p.B[0] = o.E2; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = o.dE1; p.cm = plain(D); p.cn = plain(1);
-        CKI(gemm(p, true, false, 0, st));
+        CKI(gemm(p, true, false, 0, ROLE_MISC, st));
     }
     {   // dE2 = dLs^T E1
         GemmP p = gp();
@@ -326,7 +349,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.A[0] = o.dLs; p.am = plain(1); p.ak = plain(o.ldS);
         p.B[0] = o.E1; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = o.dE2; p.cm = plain(D); p.cn = plain(1);
-        CKI(gemm(p, false, false, 0, st));
+        CKI(gemm(p, false, false, 0, ROLE_MISC, st));
     }
     for (int i = 0; i < 2; ++i) {
         {   // dWe = dE Mem^T
@@ -335,7 +358,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
             p.A[0] = i ? o.dE2 : o.dE1; p.am = plain(D); p.ak = plain(1);
             p.B[0] = Mem; p.bk = plain(1); p.bn = plain(D);
             p.C[0] = i ? dWe2 : dWe1; p.cm = plain(M); p.cn = plain(1);
-            CKI(gemm(p, true, true, 0, st));
+            CKI(gemm(p, true, true, 0, ROLE_MISC, st));
         }
         {   // dMem += We^T dE
             GemmP p = gp();
@@ -344,7 +367,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
             p.B[0] = i ? o.dE2 : o.dE1; p.bk = plain(D); p.bn = plain(1);
             p.C[0] = dMem_acc; p.Cin[0] = dMem_acc; p.cm = plain(D); p.cn = plain(1);
             p.beta = 1.f;
-            CKI(gemm(p, false, false, 0, st));
+            CKI(gemm(p, false, false, 0, ROLE_MISC, st));
         }
     }
     return 0;
@@ -507,7 +530,7 @@ static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long
         p.B[0] = Wq; p.bk = plain(1); p.bn = plain(D);
         p.C[0] = dh; p.cm = plain(lddh); p.cn = plain(1);
         if (dh_accumulate) { p.Cin[0] = dh; p.beta = 1.f; }
-        CKI(gemm(p, true, true, 0, st));
+        CKI(gemm(p, true, true, 0, ROLE_MISC, st));
     }
     {
         GemmP p = gp();
@@ -516,7 +539,7 @@ static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long
         p.B[0] = dq; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = dWq_s; p.Cin[0] = dWq_s; p.cm = plain(D); p.cn = plain(1);
         p.beta = 1.f; p.slab = (long long)H * D;
-        CKI(gemm(p, false, false, NSLAB_W, st));
+        CKI(gemm(p, false, false, NSLAB_W, ROLE_MISC, st));
     }
     for (int i = 0; i < 2; ++i) {
         GemmP p = gp();
@@ -525,7 +548,7 @@ static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long
         p.B[0] = i ? q_rows : dval; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = dMem_s; p.Cin[0] = dMem_s; p.cm = plain(D); p.cn = plain(1);
         p.beta = 1.f; p.slab = (long long)M * D;
-        CKI(gemm(p, false, false, NSLAB_W, st));
+        CKI(gemm(p, false, false, NSLAB_W, ROLE_MISC, st));
     }
     return 0;
 }
@@ -619,7 +642,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         q.B[0] = P.Zdec + sd.ZT; q.bk = two((int)R, sd.ZT, sd.Cp); q.bk_hi[0] = sd.ZT; q.bn = plain(1);
         q.C[0] = P.dWp_s; q.Cin[0] = P.dWp_s; q.cm = plain(Hd); q.cn = plain(1);
         q.beta = 1.f; q.slab = (long long)od * Hd;
-        CKI(gemm(q, false, false, NSLAB_W, st));
+        CKI(gemm(q, false, false, NSLAB_W, ROLE_MISC, st));
         LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, st, g->proj_w, (const float*)P.dWp_s, NSLAB_W,
                (long long)od * Hd, (long long)od * Hd, 0);
         CKI(colsum(P.dgo, od, To * R, od, P.part, g->proj_b, 0, st));
@@ -753,6 +776,31 @@ extern "C" {
 const char* mcrn_last_error(void) { return g_err; }
 int mcrn_version(void) { return 100; }
 int mcrn_last_launch_count(void) { return g_launches; }
+
+int mcrn_prof_begin(int role) {
+    if (role < 0 || role >= ROLE_COUNT) FAIL("prof: bad role %d", role);
+    if (!g_prof.created) {
+        for (int i = 0; i < 2 * Prof::MAXEV; ++i) CK(hipEventCreate(&g_prof.ev[i]));
+        g_prof.created = true;
+    }
+    g_prof.role = role; g_prof.n = 0; g_prof.alg_flops = 0; g_prof.exec_flops = 0;
+    return 0;
+}
+int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops) {
+    double tot = 0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        float ms = 0;
+        CK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        CK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = g_prof.n;
+    if (alg_flops) *alg_flops = g_prof.alg_flops;
+    if (exec_flops) *exec_flops = g_prof.exec_flops;
+    g_prof.role = -1;
+    return 0;
+}
 
 size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d) {
     if (check_dims(d)) return 0;
@@ -1000,7 +1048,7 @@ int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, c
         if (!slabs) FAIL("gemm: nsplit > 1 needs slabs");
         CK(hipMemsetAsync(slabs, 0, (size_t)nsplit * M * N * sizeof(float), st));
         p.C[0] = slabs; p.Cin[0] = slabs; p.beta = 1.f; p.slab = (long long)M * N;
-        CKI(gemm(p, !transA, transB != 0, nsplit, st));
+        CKI(gemm(p, !transA, transB != 0, nsplit, ROLE_MISC, st));
         // C = alpha*sum(slabs) (alpha already applied) + beta*C
         if (beta == 0.f) {
             LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 0);
@@ -1012,7 +1060,7 @@ int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, c
     }
     p.C[0] = C;
     if (beta != 0.f) { p.Cin[0] = C; p.beta = beta; }
-    return gemm(p, !transA, transB != 0, 0, st);
+    return gemm(p, !transA, transB != 0, 0, ROLE_MISC, st);
 }
 
 }  // extern "C"

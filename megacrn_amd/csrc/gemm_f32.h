@@ -35,6 +35,19 @@ static inline Dim2 two(int inner, long long hi, long long lo) { return Dim2{inne
 
 enum Epi { EPI_STORE = 0, EPI_GATE = 1, EPI_UPDATE = 2, EPI_BIAS = 3 };
 
+// Role tag: only changes the kernel's symbol name so that rocprofv3 --stats reports the hot
+// contractions separately (all roles share one body).
+enum Role {
+    ROLE_MISC = 0,    // adjacency / memory head / proj odds and ends
+    ROLE_PROP = 1,    // K-hop propagation  S x Z[g]            (model/MegaCRN.py:25)   <- north_star kernel
+    ROLE_WP = 2,      // weight pool + fused GRU epilogue        (model/MegaCRN.py:27,43-47)
+    ROLE_DGRAD = 3,   // dY x W^T -> plane gradients
+    ROLE_PROPT = 4,   // S^T x dZ[g]  (backward propagation)
+    ROLE_DS = 5,      // adjacency gradient  dZ x Z^T  (split-K)
+    ROLE_WGRAD = 6,   // deferred weight gradient Z^T x dY (split-K)
+    ROLE_COUNT = 7
+};
+
 struct GemmP {
     const float* A[2];
     const float* B[2];
@@ -53,6 +66,7 @@ struct GemmP {
     float* out2;       long long out2_ld;     // GATE: z*h  ; UPDATE: new state
     const float* zr;                           // UPDATE: sigmoid gates (R x 2H)
     int H;
+    double alg_flops;   // host-side bookkeeping only (algorithmic flops of this launch)
 };
 
 __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {
@@ -124,7 +138,7 @@ struct Tile {
     }
 };
 
-template <int BM, int BN, bool AKC, bool BKC>
+template <int BM, int BN, bool AKC, bool BKC, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 32, FN = WN / 32;
@@ -258,20 +272,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 struct GemmStats { long long launches; double flops; };
 extern GemmStats g_gemm_stats;
 
-template <int BM, int BN>
-static inline hipError_t launch_cfg(const GemmP& p, bool akc, bool bkc, hipStream_t st) {
+template <int BM, int BN, bool AKC, bool BKC, int ROLE>
+static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
-    dim3 blk(256);
-    if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, blk, 0, st, p);
-    else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, blk, 0, st, p);
-    else if (!akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, blk, 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
     return hipGetLastError();
+}
+template <bool AKC, bool BKC, int ROLE>
+static inline hipError_t launch_cfg(const GemmP& p, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_one<128, 128, AKC, BKC, ROLE>(p, st);
+        case 1: return launch_one<64, 128, AKC, BKC, ROLE>(p, st);
+        case 2: return launch_one<128, 64, AKC, BKC, ROLE>(p, st);
+        default: return launch_one<64, 64, AKC, BKC, ROLE>(p, st);
+    }
+}
+static inline hipError_t launch_role(const GemmP& p, bool akc, bool bkc, int role, int cfg, hipStream_t st) {
+    // each hot role uses exactly one operand-contiguity combination; anything else goes to MISC
+    if (role == ROLE_PROP && akc && !bkc) return launch_cfg<true, false, ROLE_PROP>(p, cfg, st);
+    if (role == ROLE_WP && akc && !bkc) return launch_cfg<true, false, ROLE_WP>(p, cfg, st);
+    if (role == ROLE_DGRAD && akc && bkc) return launch_cfg<true, true, ROLE_DGRAD>(p, cfg, st);
+    if (role == ROLE_PROPT && akc && !bkc) return launch_cfg<true, false, ROLE_PROPT>(p, cfg, st);
+    if (role == ROLE_DS && akc && bkc) return launch_cfg<true, true, ROLE_DS>(p, cfg, st);
+    if (role == ROLE_WGRAD && !akc && !bkc) return launch_cfg<false, false, ROLE_WGRAD>(p, cfg, st);
+    if (akc && !bkc) return launch_cfg<true, false, ROLE_MISC>(p, cfg, st);
+    if (akc && bkc) return launch_cfg<true, true, ROLE_MISC>(p, cfg, st);
+    if (!akc && !bkc) return launch_cfg<false, false, ROLE_MISC>(p, cfg, st);
+    return launch_cfg<false, true, ROLE_MISC>(p, cfg, st);
 }
 
 // Pick tile shape and split-K.  `want_split`: 0 = never split (C is a real output), otherwise the
 // maximum number of slabs the caller provisioned behind C (stride p.slab).
-static inline hipError_t launch_gemm(GemmP p, bool akc, bool bkc, int max_split, hipStream_t st) {
+static inline hipError_t launch_gemm(GemmP p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if (p.nbatch <= 0) p.nbatch = 1;
     static const int cfg[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
@@ -303,12 +335,7 @@ static inline hipError_t launch_gemm(GemmP p, bool akc, bool bkc, int max_split,
     }
     g_gemm_stats.launches++;
     g_gemm_stats.flops += 2.0 * p.M * p.N * (double)p.K * p.nbatch;
-    switch (best) {
-        case 0: return launch_cfg<128, 128>(p, akc, bkc, st);
-        case 1: return launch_cfg<64, 128>(p, akc, bkc, st);
-        case 2: return launch_cfg<128, 64>(p, akc, bkc, st);
-        default: return launch_cfg<64, 64>(p, akc, bkc, st);
-    }
+    return launch_role(p, akc, bkc, role, best, st);
 }
 
 }  // namespace mcrn

@@ -1,0 +1,59 @@
+"""Batch data parallelism for the MegaCRN hot path: one process per GPU, samples sharded across
+ranks, parameters replicated, ONE all-reduce(sum) of the flat gradient bucket per optimizer step
+(0.5-2.8 MB, latency-bound on xGMI - SURVEY.md 5.8), then 1/world scaling inside the fused
+clip+Adam kernel.  No other exchange; the batch-independent adjacency is recomputed on every rank.
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU (tests)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT) -> (rank, local_rank, world)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend, rank=rk, world_size=ws, device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend, rank=rk, world_size=ws)
+    return rk, lr, ws
+
+
+def shard_bounds(global_batch: int, rk: int, ws: int) -> tuple[int, int]:
+    """rank r owns the r-th block of consecutive samples (sizes differ by at most one)."""
+    base, rem = divmod(global_batch, ws)
+    lo = rk * base + min(rk, rem)
+    return lo, lo + base + (1 if rk < rem else 0)
+
+
+def allreduce_flat(flat_g: torch.Tensor, group=None) -> None:
+    dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)
+
+
+def broadcast_flat(flat_p: torch.Tensor, group=None, src: int = 0) -> None:
+    dist.broadcast(flat_p, src=src, group=group)
+
+
+def seed_curriculum(seed: int) -> None:
+    """The curriculum draw is one np.random.uniform() per decoder step for the whole batch
+    (model/MegaCRN.py:189): every rank must consume the same stream, so all ranks use `seed`."""
+    np.random.seed(seed)

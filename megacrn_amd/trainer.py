@@ -1,0 +1,124 @@
+"""Train step of the reference trainer (model/traintest_MegaCRN.py:115-130) on the HIP hot path.
+
+One step = forward (C ABI) -> 3-term loss (:118-125) -> backward (C ABI, gradients written straight
+into one flat fp32 bucket) -> ONE all-reduce(sum) of that bucket over RCCL when world_size > 1 ->
+clip_grad_norm_(5) + Adam(lr, eps=1e-3) as a single flat HIP kernel pair.  Parameters stay ordinary
+``nn.Parameter``s of the reference shapes (views into the flat buffer), so ``state_dict`` round-trips.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib, check, Dims, Params, Grads
+from . import dp
+
+
+def masked_mae_loss(y_pred, y_true):
+    """model/utils.py:126-133 (no in-place NaN patching needed: mask.mean()==0 is the only NaN source)."""
+    mask = (y_true != 0).float()
+    mask = mask / mask.mean()
+    loss = torch.abs(y_pred - y_true) * mask
+    loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+    return loss.mean()
+
+
+class FlatTrainer:
+    def __init__(self, model, *, lr=0.01, eps=1e-3, betas=(0.9, 0.999), max_grad_norm=5.0, lamb=0.01,
+                 lamb1=0.01, scaler_mean=0.0, scaler_std=1.0, process_group=None):
+        if model.num_layers != 1:
+            raise ValueError("FlatTrainer drives the fused num_layers==1 path")
+        self.model = model
+        self.lr, self.eps, self.betas, self.max_grad_norm = lr, eps, betas, float(max_grad_norm)
+        self.lamb, self.lamb1 = lamb, lamb1
+        self.mean, self.std = float(scaler_mean), float(scaler_std)
+        self.group = process_group
+        self.world = dp.world_size(process_group)
+        params = list(model._fused_params())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatTrainer needs the model on a HIP device (no CPU fallback)")
+        sizes = [p.numel() for p in params]
+        # 64-float (256 B) aligned slices so every tensor keeps the alignment torch would give it
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += (n + 63) // 64 * 64
+        self.n = o
+        self.flat_p = torch.zeros(o, device=dev)
+        self.flat_g = torch.zeros(o, device=dev)
+        self.m = torch.zeros(o, device=dev)
+        self.v = torch.zeros(o, device=dev)
+        self.scratch = torch.zeros(2048, device=dev)
+        self.total_norm = torch.zeros(1, device=dev)
+        self._gviews = []
+        for p, off, n in zip(params, offs, sizes):
+            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            self._gviews.append(self.flat_g[off:off + n].view(p.shape))
+        self.params = params
+        if self.world > 1:
+            dp.broadcast_flat(self.flat_p, process_group)      # identical weights on every rank
+        self.step_count = 0
+        self.batches_seen = 0
+        self._ws = None
+        self._dims_key = None
+        self.triplet = nn.TripletMarginLoss(margin=1.0)
+        self.mse = nn.MSELoss()
+
+    # -- buffers sized for one batch shape, reused across steps
+    def _prepare(self, x):
+        m = self.model
+        key = (x.shape[0], x.shape[1])
+        if key != self._dims_key:
+            self.d = Dims(x.shape[0], m.num_nodes, x.shape[1], m.horizon, m.input_dim, m.output_dim, m.ycov_dim,
+                          m.rnn_units, m.mem_num, m.mem_dim, m.cheb_k, 0)
+            nb = lib.mcrn_model_workspace_bytes(C.byref(self.d))
+            if nb == 0:
+                raise ValueError(lib.mcrn_last_error().decode())
+            dev = x.device
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            B, N, To, od, D = self.d.B, self.d.N, self.d.T_out, self.d.output_dim, self.d.mem_dim
+            self.out = torch.empty(B, To, N, od, device=dev)
+            self.hatt, self.q, self.pos, self.neg = (torch.empty(B, N, D, device=dev) for _ in range(4))
+            self._dims_key = key
+
+    def loss_fn(self, output, query, pos, neg, labels):
+        y_pred = output * self.std + self.mean            # scaler.inverse_transform (:118-119)
+        y_true = labels * self.std + self.mean
+        loss1 = masked_mae_loss(y_pred, y_true)
+        loss2 = self.triplet(query, pos, neg)             # pos/neg are detached (:123)
+        loss3 = self.mse(query, pos)
+        return loss1 + self.lamb * loss2 + self.lamb1 * loss3
+
+    def train_step(self, x, ycov, labels):
+        """One optimizer step; returns the (device) loss tensor without synchronising."""
+        m = self.model
+        self._prepare(x)
+        st = torch.cuda.current_stream().cuda_stream
+        teacher = m._teacher_flags(labels, self.batches_seen)
+        tarr = (C.c_int * m.horizon)(*[int(f) for f in teacher])
+        ps = Params(*[p.data_ptr() for p in self.params])
+        gs = Grads(*[g.data_ptr() for g in self._gviews])
+        nb = self._ws.numel()
+        check(lib.mcrn_model_forward(C.byref(self.d), C.byref(ps), x.data_ptr(), ycov.data_ptr(), labels.data_ptr(),
+                                     tarr, self._ws.data_ptr(), nb, self.out.data_ptr(), self.hatt.data_ptr(),
+                                     self.q.data_ptr(), self.pos.data_ptr(), self.neg.data_ptr(), st),
+              "mcrn_model_forward")
+        out_l = self.out.detach().requires_grad_()
+        q_l = self.q.detach().requires_grad_()
+        loss = self.loss_fn(out_l, q_l, self.pos, self.neg, labels)
+        d_out, d_q = torch.autograd.grad(loss, [out_l, q_l])
+        check(lib.mcrn_model_backward(C.byref(self.d), C.byref(ps), tarr, d_out.data_ptr(), None, d_q.data_ptr(),
+                                      None, None, self._ws.data_ptr(), nb, C.byref(gs), st), "mcrn_model_backward")
+        if self.world > 1:
+            dp.allreduce_flat(self.flat_g, self.group)       # the single collective of the step
+        self.step_count += 1
+        check(lib.mcrn_flat_clip_adam(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
+                                      self.v.data_ptr(), self.n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                      self.step_count, self.max_grad_norm, 1.0 / self.world,
+                                      self.scratch.data_ptr(), self.total_norm.data_ptr(), st), "mcrn_flat_clip_adam")
+        self.batches_seen += 1
+        return loss.detach()
