@@ -37,7 +37,9 @@ extern "C" {
 #define MCRN_EINVAL (-1)
 
 /* compute precision of the MFMA contractions */
-#define MCRN_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define MCRN_F32 0     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 157 TF peak */
+#define MCRN_BF16X3 1  /* fp32 operands split into bf16 hi+lo, 3x v_mfma_f32_32x32x16_bf16 with fp32
+                          accumulate: ~1e-5 relative error, 5.3x the MFMA rate of MCRN_F32 (default) */
 
 typedef struct mcrn_dims {
     int B;          /* batch */
@@ -51,7 +53,7 @@ typedef struct mcrn_dims {
     int mem_num;    /* M */
     int mem_dim;    /* D */
     int cheb_k;     /* 2 or 3 */
-    int precision;  /* MCRN_F32 */
+    int precision;  /* MCRN_F32 or MCRN_BF16X3 */
 } mcrn_dims_t;
 
 /* parameter pointers, named after the reference state_dict keys (num_layers=1) */
@@ -73,6 +75,11 @@ typedef struct mcrn_grads {
 
 const char* mcrn_last_error(void);
 int mcrn_version(void);
+
+/* arithmetic used by the stand-alone op entry points (the model entry points take it from
+ * mcrn_dims_t.precision).  Returns 0 or MCRN_EINVAL. */
+int mcrn_set_precision(int precision);
+int mcrn_get_precision(void);
 
 /* ---- whole model: MegaCRN.forward, model/MegaCRN.py:168-194, and its autograd backward ---- */
 size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d);
@@ -162,6 +169,8 @@ int mcrn_last_launch_count(void);
  * mcrn_prof_end synchronises on the recorded events and returns the summed kernel time, the number
  * of launches, their algorithmic flops (true channel counts) and executed flops. */
 int mcrn_prof_begin(int role);
+/* tuning hook: force GEMM tile configuration 0..6 for every launch (-1 = automatic) */
+int mcrn_set_gemm_cfg(int cfg);
 int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end",
+    "mcrn_flat_clip_adam", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_precision", "mcrn_get_precision",
 ]
 
 
@@ -98,6 +98,11 @@ def _load():
     lib.mcrn_gemm_f32.argtypes = [i, i, i, i, i, vp, vp, vp, f, f, i, vp, vp]
     lib.mcrn_prof_begin.restype = i
     lib.mcrn_prof_begin.argtypes = [i]
+    lib.mcrn_set_precision.restype = i
+    lib.mcrn_set_precision.argtypes = [i]
+    lib.mcrn_get_precision.restype = i
+    lib.mcrn_set_gemm_cfg.restype = i
+    lib.mcrn_set_gemm_cfg.argtypes = [i]
     lib.mcrn_prof_end.restype = i
     lib.mcrn_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]
@@ -105,6 +110,19 @@ def _load():
 
 
 lib = _load()
+
+F32, BF16X3 = 0, 1
+PRECISIONS = {"f32": F32, "bf16x3": BF16X3}
+
+
+def default_precision() -> int:
+    """MEGACRN_PRECISION=f32|bf16x3 (default bf16x3: fp32-equivalent split on the bf16 matrix cores)."""
+    return PRECISIONS[os.environ.get("MEGACRN_PRECISION", "bf16x3")]
+
+
+def set_precision(name_or_id) -> None:
+    v = PRECISIONS[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+    check(lib.mcrn_set_precision(v), "mcrn_set_precision")
 
 
 def check(rc: int, what: str) -> None:

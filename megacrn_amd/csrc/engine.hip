@@ -17,11 +17,14 @@
 
 #include "../../include/megacrn_hip.h"
 #include "gemm_f32.h"
+#include "gemm_bf16x3.h"
 #include "ops.h"
 
 namespace mcrn {
 
 GemmStats g_gemm_stats = {0, 0.0};
+int g_force_cfg = -1;
+static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch
 static char g_err[512] = "";
 static int g_launches = 0;
 
@@ -71,7 +74,8 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
     ++g_launches;
     const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
     if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
-    CK(launch_gemm(p, akc, bkc, max_split, role, st));
+    if (g_precision == MCRN_BF16X3) CK(launch_gemm_x3(p, akc, bkc, max_split, role, st));
+    else CK(launch_gemm_f32(p, akc, bkc, max_split, st));
     if (prof) {
         CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
         const double ex = 2.0 * p.M * p.N * (double)p.K * p.nbatch;
@@ -426,7 +430,7 @@ static int check_dims(const mcrn_dims_t* d) {
         d->ycov_dim < 0 || d->H < 1 || d->mem_num < 1 || d->mem_dim < 1)
         FAIL("mcrn_dims: all sizes must be >= 1");
     if (d->cheb_k != 2 && d->cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", d->cheb_k);
-    if (d->precision != MCRN_F32) FAIL("unsupported precision %d", d->precision);
+    if (d->precision != MCRN_F32 && d->precision != MCRN_BF16X3) FAIL("unsupported precision %d", d->precision);
     return 0;
 }
 
@@ -777,6 +781,14 @@ const char* mcrn_last_error(void) { return g_err; }
 int mcrn_version(void) { return 100; }
 int mcrn_last_launch_count(void) { return g_launches; }
 
+int mcrn_set_gemm_cfg(int cfg) { g_force_cfg = cfg; return 0; }
+int mcrn_set_precision(int precision) {
+    if (precision != MCRN_F32 && precision != MCRN_BF16X3) FAIL("unsupported precision %d", precision);
+    g_precision = precision;
+    return 0;
+}
+int mcrn_get_precision(void) { return g_precision; }
+
 int mcrn_prof_begin(int role) {
     if (role < 0 || role >= ROLE_COUNT) FAIL("prof: bad role %d", role);
     if (!g_prof.created) {
@@ -818,6 +830,7 @@ int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float
     if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small: %zu < %zu", ws_bytes, mcrn_model_workspace_bytes(d));
     if (teacher && !labels) for (int t = 0; t < d->T_out; ++t) if (teacher[t]) FAIL("teacher forcing requested without labels");
     g_launches = 0;
+    g_precision = d->precision;
     return model_forward(d, p, x, ycov, labels, teacher, (char*)ws, output, h_att, query, pos, neg, (hipStream_t)stream);
 }
 
@@ -827,6 +840,7 @@ int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int*
     CKI(check_dims(d));
     if (!p || !d_output || !ws || !grads) FAIL("mcrn_model_backward: NULL argument");
     if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small");
+    g_precision = d->precision;
     return model_backward(d, p, teacher, d_output, d_hatt, d_query, d_pos, d_neg, (char*)ws, grads, (hipStream_t)stream);
 }
 

@@ -1,0 +1,262 @@
+// gemm_bf16x3.h - fp32-equivalent GEMM on the bf16 matrix cores of gfx950 (wave64).
+//
+// Every fp32 operand element x is split on the fly into two bf16 values  hi = bf16(x),
+// lo = bf16(x - hi)  (16 mantissa bits together) and the product is evaluated as
+//     A*B ~= Ahi*Bhi + Ahi*Blo + Alo*Bhi          (fp32 accumulate in the MFMA)
+// with v_mfma_f32_32x32x16_bf16: three MFMAs at 16x the fp32-MFMA rate = 5.3x the throughput of
+// the exact v_mfma_f32_32x32x2_f32 path (gemm_f32.h) at an error of ~1e-5 relative (the dropped
+// lo*lo term is 2^-16 of the product), an order of magnitude inside the 1e-4 parity budget.
+// Storage stays fp32; the split costs ~3 VALU ops per loaded element and every element is reused
+// BM (or BN) times.
+//
+// Same GemmP interface / index maps / fused epilogues as gemm_f32.h.  Differences:
+//   BK = 32.  A thread owns (row, 8 consecutive k) of an operand tile: K-contiguous sources are
+//   fetched as two float4 per thread, row-contiguous sources as 8 coalesced dwords (the transposition
+//   to "k-contiguous per lane" that the bf16 MFMA wants happens in registers), converted, and stored
+//   as one 16-byte hi and one 16-byte lo vector into LDS images [row][32 bf16 + 8 pad] (80-byte
+//   rows: conflict-free for ds_write_b128 and for the ds_read_b128 fragment reads).
+#pragma once
+#include "gemm_f32.h"
+
+namespace mcrn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// 8 fp32 -> 8 bf16 hi + 8 bf16 lo (round-to-nearest-even twice)
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned r = cvt_pk_bf16(v[2 * j], v[2 * j + 1]);
+        const float h0 = __uint_as_float(r << 16), h1 = __uint_as_float(r & 0xFFFF0000u);
+        h[j] = r;
+        l[j] = cvt_pk_bf16(v[2 * j] - h0, v[2 * j + 1] - h1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ---- operand tile: E rows x 32 k ; thread owns NP (row, k-group-of-8) pairs -------------------
+template <int E, bool KC>
+struct TileX {
+    static constexpr int NP = (E * 4 + 255) / 256;
+    static constexpr int SZ = E * 5;            // uint4 per image (80-byte rows)
+    long long roff[NP];
+    int row[NP], kg[NP];
+    float v[NP][8];
+
+    __device__ __forceinline__ void init_rows(int tid, int row0, int nrows, const Dim2& d) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int pi = tid + 256 * q;
+            int r, g;
+            if (KC) { r = pi >> 2; g = pi & 3; } else { r = pi % E; g = pi / E; }
+            row[q] = r; kg[q] = g;
+            const int gr = row0 + r;
+            roff[q] = (pi < E * 4 && gr < nrows) ? d2off(d.inner, d.hi, d.lo, gr) : -1;
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ base, int k0, int kend, int kinner,
+                                         long long khi, long long klo, bool vec) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int k = k0 + 8 * kg[q];
+            if (roff[q] < 0 || k >= kend) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[q][j] = 0.f;
+                continue;
+            }
+            const float* __restrict__ rp = base + roff[q];
+            if (KC) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int kk = k + 4 * h;
+                    if (vec && kk + 3 < kend) {        // 4 consecutive k are contiguous and 16-B aligned
+                        const float4 t = *reinterpret_cast<const float4*>(rp + d2off(kinner, khi, klo, kk));
+                        v[q][4 * h] = t.x; v[q][4 * h + 1] = t.y; v[q][4 * h + 2] = t.z; v[q][4 * h + 3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[q][4 * h + j] = (kk + j < kend) ? rp[d2off(kinner, khi, klo, kk + j)] : 0.f;
+                    }
+                }
+            } else {
+                if (kinner <= 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[q][j] = (k + j < kend) ? rp[(long long)(k + j) * klo] : 0.f;
+                } else {
+                    int qd = k / kinner, rm = k - qd * kinner;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[q][j] = (k + j < kend) ? rp[(long long)qd * khi + (long long)rm * klo] : 0.f;
+                        if (++rm == kinner) { rm = 0; ++qd; }
+                    }
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(uint4* sHi, uint4* sLo, int tid) const {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (tid + 256 * q < E * 4) {
+                uint4 h, l;
+                split8(v[q], h, l);
+                sHi[row[q] * 5 + kg[q]] = h;
+                sLo[row[q] * 5 + kg[q]] = l;
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    using TA = TileX<BM, AKC>;
+    using TB = TileX<BN, BKC>;
+    __shared__ uint4 smem[2 * TA::SZ + 2 * TB::SZ];
+    uint4* sAh = smem;
+    uint4* sAl = smem + TA::SZ;
+    uint4* sBh = smem + 2 * TA::SZ;
+    uint4* sBl = smem + 2 * TA::SZ + TB::SZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int z = blockIdx.z;
+    const int batch = z / p.nsplit, split = z - batch * p.nsplit;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+
+    const float* __restrict__ Ab = p.A[batch];
+    const float* __restrict__ Bb = p.B[batch];
+    const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
+    const bool avec = (p.vec & 1) != 0, bvec = (p.vec & 2) != 0;
+
+    TA ta;
+    TB tb;
+    ta.init_rows(tid, m_blk, p.M, p.am);
+    tb.init_rows(tid, n_blk, p.N, p.bn);
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    ta.load(Ab, kbeg, kend, p.ak.inner, akhi, p.ak.lo, avec);
+    tb.load(Bb, kbeg, kend, p.bk.inner, bkhi, p.bk.lo, bvec);
+    ta.store(sAh, sAl, tid);
+    tb.store(sBh, sBl, tid);
+    __syncthreads();
+
+    const int l31 = lane & 31, kq = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        const bool more = k0 + 32 < kend;
+        if (more) {
+            ta.load(Ab, k0 + 32, kend, p.ak.inner, akhi, p.ak.lo, avec);
+            tb.load(Bb, k0 + 32, kend, p.bk.inner, bkhi, p.bk.lo, bvec);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int o = (wm * WM + i * 32 + l31) * 5 + ks * 2 + kq;
+                ah[i] = __builtin_bit_cast(bf16x8, sAh[o]);
+                al[i] = __builtin_bit_cast(bf16x8, sAl[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int o = (wn * WN + j * 32 + l31) * 5 + ks * 2 + kq;
+                bh[j] = __builtin_bit_cast(bf16x8, sBh[o]);
+                bl[j] = __builtin_bit_cast(bf16x8, sBl[o]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            ta.store(sAh, sAl, tid);
+            tb.store(sBh, sBl, tid);
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kq, n_blk + wn * WN + l31);
+}
+
+// ---- host launcher ------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
+static inline hipError_t launch_one_x3(const GemmP& p, hipStream_t st) {
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+template <bool AKC, bool BKC, int ROLE>
+static inline hipError_t launch_cfg_x3(const GemmP& p, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_one_x3<128, 128, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 1: return launch_one_x3<64, 128, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 2: return launch_one_x3<128, 64, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 3: return launch_one_x3<64, 64, 2, 2, AKC, BKC, ROLE>(p, st);
+        default: return launch_one_x3<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
+    }
+}
+static inline hipError_t launch_role_x3(const GemmP& p, bool akc, bool bkc, int role, int cfg, hipStream_t st) {
+    // each hot role uses exactly one operand-contiguity combination; anything else goes to MISC
+    if (role == ROLE_PROP && akc && !bkc) return launch_cfg_x3<true, false, ROLE_PROP>(p, cfg, st);
+    if (role == ROLE_WP && akc && !bkc) return launch_cfg_x3<true, false, ROLE_WP>(p, cfg, st);
+    if (role == ROLE_DGRAD && akc && bkc) return launch_cfg_x3<true, true, ROLE_DGRAD>(p, cfg, st);
+    if (role == ROLE_PROPT && akc && !bkc) return launch_cfg_x3<true, false, ROLE_PROPT>(p, cfg, st);
+    if (role == ROLE_DS && akc && bkc) return launch_cfg_x3<true, true, ROLE_DS>(p, cfg, st);
+    if (role == ROLE_WGRAD && !akc && !bkc) return launch_cfg_x3<false, false, ROLE_WGRAD>(p, cfg, st);
+    if (akc && !bkc) return launch_cfg_x3<true, false, ROLE_MISC>(p, cfg, st);
+    if (akc && bkc) return launch_cfg_x3<true, true, ROLE_MISC>(p, cfg, st);
+    if (!akc && !bkc) return launch_cfg_x3<false, false, ROLE_MISC>(p, cfg, st);
+    return launch_cfg_x3<false, true, ROLE_MISC>(p, cfg, st);
+}
+
+// float4 eligibility of a K-contiguous operand: unit k stride, every 4-group of k (k % 4 == 0)
+// contiguous and 16-byte aligned for every row of every batch.
+static inline bool vec_ok(const float* const* bases, int nbatch, const Dim2& rows, const Dim2& k,
+                          const long long* khi) {
+    if (k.lo != 1) return false;
+    for (int b = 0; b < nbatch; ++b) {
+        if (((uintptr_t)bases[b]) & 15) return false;
+        if (k.inner > 0 && (khi[b] & 3)) return false;
+    }
+    if (k.inner > 0 && (k.inner & 3)) return false;
+    if (rows.lo & 3) return false;
+    if (rows.inner > 0 && (rows.hi & 3)) return false;
+    return true;
+}
+
+static inline hipError_t launch_gemm_x3(GemmP p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    const int cfg = choose_cfg(p, max_split, 32);
+    p.vec = 0;
+    if (akc && vec_ok(p.A, p.nbatch, p.am, p.ak, p.ak_hi)) p.vec |= 1;
+    if (bkc && vec_ok(p.B, p.nbatch, p.bn, p.bk, p.bk_hi)) p.vec |= 2;
+    return launch_role_x3(p, akc, bkc, role, cfg, st);
+}
+
+}  // namespace mcrn

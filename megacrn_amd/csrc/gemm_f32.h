@@ -67,12 +67,71 @@ struct GemmP {
     const float* zr;                           // UPDATE: sigmoid gates (R x 2H)
     int H;
     double alg_flops;   // host-side bookkeeping only (algorithmic flops of this launch)
+    int vec;            // bf16x3 path: bit0 = A rows float4-loadable, bit1 = B
 };
 
 __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {
     if (inner <= 0) return (long long)i * lo;
     int q = i / inner;
     return (long long)q * hi + (long long)(i - q * inner) * lo;
+}
+
+// ---- shared epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], int batch, int split,
+                                              int r_base, int c_base) {
+    float* __restrict__ Cb = p.C[batch] + (long long)split * p.slab;
+    const float* __restrict__ Cin = p.Cin[batch] ? p.Cin[batch] + (long long)split * p.slab : nullptr;
+#define MCRN_EPI_LOOP(BODY)                                                            \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                  \
+        const int c = c_base + j * 32;                                                 \
+        if (c < p.N) {                                                                 \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                          \
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) {                      \
+                    const int r = r_base + i * 32 + (v & 3) + 8 * (v >> 2);            \
+                    if (r < p.M) {                                                     \
+                        const float a = acc[i][j][v];                                  \
+                        BODY                                                           \
+                    }                                                                  \
+                }                                                                      \
+            }                                                                          \
+        }                                                                              \
+    }
+    if (p.epi == EPI_STORE) {
+        if (Cin) {
+            MCRN_EPI_LOOP({
+                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                Cb[off] = p.alpha * a + p.beta * Cin[off];
+            })
+        } else {
+            MCRN_EPI_LOOP({
+                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                Cb[off] = p.alpha * a;
+            })
+        }
+    } else if (p.epi == EPI_BIAS) {
+        MCRN_EPI_LOOP({
+            const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+            Cb[off] = a + p.bias[c];
+        })
+    } else if (p.epi == EPI_GATE) {
+        // z_r = sigmoid(AGCN_gate) ; candidate state input = z*h   (MegaCRN.py:43-45)
+        MCRN_EPI_LOOP({
+            const float g = 1.f / (1.f + expf(-(a + p.bias[c])));
+            Cb[(long long)r * (2 * p.H) + c] = g;
+            if (c < p.H) p.out2[(long long)r * p.out2_ld + c] = g * p.hsrc[(long long)r * p.hsrc_ld + c];
+        })
+    } else {
+        // hc = tanh(AGCN_update) ; h' = r*h + (1-r)*hc               (MegaCRN.py:46-47)
+        MCRN_EPI_LOOP({
+            const float hc = tanhf(a + p.bias[c]);
+            Cb[(long long)r * p.H + c] = hc;
+            const float rg = p.zr[(long long)r * (2 * p.H) + p.H + c];
+            const float h = p.hsrc[(long long)r * p.hsrc_ld + c];
+            p.out2[(long long)r * p.out2_ld + c] = rg * h + (1.f - rg) * hc;
+        })
+    }
+#undef MCRN_EPI_LOOP
 }
 
 // ---- operand tile: E rows (m or n) x 16 k ------------------------------------------------
@@ -138,9 +197,10 @@ struct Tile {
     }
 };
 
-template <int BM, int BN, bool AKC, bool BKC, int ROLE>
+template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 32, FN = WN / 32;
     using TA = Tile<BM, AKC>;
     using TB = Tile<BN, BKC>;
@@ -150,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
@@ -211,131 +271,79 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         }
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
-    float* __restrict__ Cb = p.C[batch] + (long long)split * p.slab;
-    const float* __restrict__ Cin = p.Cin[batch] ? p.Cin[batch] + (long long)split * p.slab : nullptr;
-    const int r_base = m_blk + wm * WM + 4 * kh;
-    const int c_base = n_blk + wn * WN + l31;
-#define MCRN_EPI_LOOP(BODY)                                                            \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                  \
-        const int c = c_base + j * 32;                                                 \
-        if (c < p.N) {                                                                 \
-            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                          \
-                _Pragma("unroll") for (int v = 0; v < 16; ++v) {                      \
-                    const int r = r_base + i * 32 + (v & 3) + 8 * (v >> 2);            \
-                    if (r < p.M) {                                                     \
-                        const float a = acc[i][j][v];                                  \
-                        BODY                                                           \
-                    }                                                                  \
-                }                                                                      \
-            }                                                                          \
-        }                                                                              \
-    }
-    if (p.epi == EPI_STORE) {
-        if (Cin) {
-            MCRN_EPI_LOOP({
-                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
-                Cb[off] = p.alpha * a + p.beta * Cin[off];
-            })
-        } else {
-            MCRN_EPI_LOOP({
-                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
-                Cb[off] = p.alpha * a;
-            })
-        }
-    } else if (p.epi == EPI_BIAS) {
-        MCRN_EPI_LOOP({
-            const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
-            Cb[off] = a + p.bias[c];
-        })
-    } else if (p.epi == EPI_GATE) {
-        // z_r = sigmoid(AGCN_gate) ; candidate state input = z*h   (MegaCRN.py:43-45)
-        MCRN_EPI_LOOP({
-            const float g = 1.f / (1.f + expf(-(a + p.bias[c])));
-            Cb[(long long)r * (2 * p.H) + c] = g;
-            if (c < p.H) p.out2[(long long)r * p.out2_ld + c] = g * p.hsrc[(long long)r * p.hsrc_ld + c];
-        })
-    } else {
-        // hc = tanh(AGCN_update) ; h' = r*h + (1-r)*hc               (MegaCRN.py:46-47)
-        MCRN_EPI_LOOP({
-            const float hc = tanhf(a + p.bias[c]);
-            Cb[(long long)r * p.H + c] = hc;
-            const float rg = p.zr[(long long)r * (2 * p.H) + p.H + c];
-            const float h = p.hsrc[(long long)r * p.hsrc_ld + c];
-            p.out2[(long long)r * p.out2_ld + c] = rg * h + (1.f - rg) * hc;
-        })
-    }
-#undef MCRN_EPI_LOOP
+    gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kh, n_blk + wn * WN + l31);
 }
 
 // ---- host launcher ------------------------------------------------------------------------
 struct GemmStats { long long launches; double flops; };
 extern GemmStats g_gemm_stats;
+extern int g_force_cfg;   // >= 0: force this tile configuration (tuning sweeps)
 
-template <int BM, int BN, bool AKC, bool BKC, int ROLE>
+template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
     return hipGetLastError();
 }
+// tile configurations: {BM, BN, waves in M, waves in N}
+static const int NCFG = 5;
+static const int kCfg[NCFG][4] = {{128, 128, 2, 2}, {64, 128, 2, 2}, {128, 64, 2, 2}, {64, 64, 2, 2},
+                                  {32, 128, 1, 4}};
 template <bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_cfg(const GemmP& p, int cfg, hipStream_t st) {
     switch (cfg) {
-        case 0: return launch_one<128, 128, AKC, BKC, ROLE>(p, st);
-        case 1: return launch_one<64, 128, AKC, BKC, ROLE>(p, st);
-        case 2: return launch_one<128, 64, AKC, BKC, ROLE>(p, st);
-        default: return launch_one<64, 64, AKC, BKC, ROLE>(p, st);
+        case 0: return launch_one<128, 128, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 1: return launch_one<64, 128, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 2: return launch_one<128, 64, 2, 2, AKC, BKC, ROLE>(p, st);
+        case 3: return launch_one<64, 64, 2, 2, AKC, BKC, ROLE>(p, st);
+        default: return launch_one<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
     }
 }
-static inline hipError_t launch_role(const GemmP& p, bool akc, bool bkc, int role, int cfg, hipStream_t st) {
-    // each hot role uses exactly one operand-contiguity combination; anything else goes to MISC
-    if (role == ROLE_PROP && akc && !bkc) return launch_cfg<true, false, ROLE_PROP>(p, cfg, st);
-    if (role == ROLE_WP && akc && !bkc) return launch_cfg<true, false, ROLE_WP>(p, cfg, st);
-    if (role == ROLE_DGRAD && akc && bkc) return launch_cfg<true, true, ROLE_DGRAD>(p, cfg, st);
-    if (role == ROLE_PROPT && akc && !bkc) return launch_cfg<true, false, ROLE_PROPT>(p, cfg, st);
-    if (role == ROLE_DS && akc && bkc) return launch_cfg<true, true, ROLE_DS>(p, cfg, st);
-    if (role == ROLE_WGRAD && !akc && !bkc) return launch_cfg<false, false, ROLE_WGRAD>(p, cfg, st);
+static inline hipError_t launch_f32(const GemmP& p, bool akc, bool bkc, int cfg, hipStream_t st) {
     if (akc && !bkc) return launch_cfg<true, false, ROLE_MISC>(p, cfg, st);
     if (akc && bkc) return launch_cfg<true, true, ROLE_MISC>(p, cfg, st);
     if (!akc && !bkc) return launch_cfg<false, false, ROLE_MISC>(p, cfg, st);
     return launch_cfg<false, true, ROLE_MISC>(p, cfg, st);
 }
 
-// Pick tile shape and split-K.  `want_split`: 0 = never split (C is a real output), otherwise the
-// maximum number of slabs the caller provisioned behind C (stride p.slab).
-static inline hipError_t launch_gemm(GemmP p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+// Pick tile shape and split-K.  max_split: 0 = never split (C is a real output), otherwise the
+// number of slabs the caller provisioned behind C (stride p.slab).  kgran = K-tile depth.
+static inline int choose_cfg(GemmP& p, int max_split, int kgran) {
     if (p.nbatch <= 0) p.nbatch = 1;
-    static const int cfg[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    static const double eff[4] = {1.00, 0.90, 0.90, 0.80};
-    const double slots = 256.0 * 2.0;   // CUs x resident blocks
+    static const double eff[NCFG] = {1.00, 0.92, 0.92, 0.85, 0.80};
     int best = 3, best_split = 1;
     double best_t = 1e300;
-    for (int i = 0; i < 4; ++i) {
-        const int bm = cfg[i][0], bn = cfg[i][1];
+    for (int i = 0; i < NCFG; ++i) {
+        if (g_force_cfg >= 0 && i != g_force_cfg) continue;
+        const int bm = kCfg[i][0], bn = kCfg[i][1];
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch;
         int ns = 1;
         if (max_split > 1) {
-            ns = (int)((slots + tiles - 1) / tiles);
+            ns = (int)((512 + tiles - 1) / tiles);
             if (ns > max_split) ns = max_split;
             int maxk = p.K / 64;
             if (maxk < 1) maxk = 1;
             if (ns > maxk) ns = maxk;
             if (ns < 1) ns = 1;
         }
-        const double waves = ceil((double)tiles * ns / slots);
-        const double t = waves * (double)bm * bn * ((double)p.K / ns + 32.0) / eff[i];
+        // MFMA-bound model: a CU retires one workgroup-tile per (bm*bn*K) MFMA cycles regardless of
+        // how many are resident, so time ~ ceil(tiles / 256 CUs) * tile work (+ fixed per-tile cost)
+        const double rounds = ceil((double)tiles * ns / 256.0);
+        const double t = rounds * ((double)bm * bn * ((double)p.K / ns) + 6000.0 * 16) / eff[i];
         if (t < best_t) { best_t = t; best = i; best_split = ns; }
     }
-    int kchunk = ((p.K + best_split - 1) / best_split + 15) / 16 * 16;
+    int kchunk = ((p.K + best_split - 1) / best_split + kgran - 1) / kgran * kgran;
     p.nsplit = (p.K + kchunk - 1) / kchunk;
     p.kchunk = kchunk;
-    if (max_split > 1 && p.nsplit < max_split) {
-        // unused slabs must not hold stale data: caller zero-fills or reduces only p.nsplit slabs.
-    }
     g_gemm_stats.launches++;
     g_gemm_stats.flops += 2.0 * p.M * p.N * (double)p.K * p.nbatch;
-    return launch_role(p, akc, bkc, role, best, st);
+    return best;
+}
+
+static inline hipError_t launch_gemm_f32(GemmP p, bool akc, bool bkc, int max_split, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    const int cfg = choose_cfg(p, max_split, 16);
+    return launch_f32(p, akc, bkc, cfg, st);
 }
 
 }  // namespace mcrn

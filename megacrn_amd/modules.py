@@ -363,6 +363,7 @@ class MegaCRN(nn.Module):
         self.ycov_dim = ycov_dim
         self.cl_decay_steps = cl_decay_steps
         self.use_curriculum_learning = use_curriculum_learning
+        self.precision = _lib.default_precision()   # _lib.F32 (exact) or _lib.BF16X3
 
         # memory
         self.mem_num = mem_num
@@ -422,7 +423,7 @@ class MegaCRN(nn.Module):
             if any(teacher) and labels is None:
                 raise ValueError("curriculum learning needs labels")
             d = Dims(x.shape[0], self.num_nodes, x.shape[1], self.horizon, self.input_dim, self.output_dim,
-                     self.ycov_dim, self.rnn_units, self.mem_num, self.mem_dim, self.cheb_k, 0)
+                     self.ycov_dim, self.rnn_units, self.mem_num, self.mem_dim, self.cheb_k, self.precision)
             assert x.shape[2] == self.num_nodes and x.shape[3] == self.input_dim
             return _ModelFn.apply(d, teacher, x, y_cov, labels, *self._fused_params())
         return self._forward_composed(x, y_cov, labels, batches_seen)

@@ -74,7 +74,7 @@ class FlatTrainer:
         key = (x.shape[0], x.shape[1])
         if key != self._dims_key:
             self.d = Dims(x.shape[0], m.num_nodes, x.shape[1], m.horizon, m.input_dim, m.output_dim, m.ycov_dim,
-                          m.rnn_units, m.mem_num, m.mem_dim, m.cheb_k, 0)
+                          m.rnn_units, m.mem_num, m.mem_dim, m.cheb_k, m.precision)
             nb = lib.mcrn_model_workspace_bytes(C.byref(self.d))
             if nb == 0:
                 raise ValueError(lib.mcrn_last_error().decode())

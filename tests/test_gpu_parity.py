@@ -17,11 +17,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def amd():
+@pytest.fixture(params=["bf16x3", "f32"])
+def amd(request):
+    """The package, with the contraction arithmetic set to each supported precision in turn:
+    bf16x3 (default; fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs, fp32 accumulate) and
+    f32 (exact fp32 MFMA).  Both must meet the same 1e-4 tolerance."""
     import megacrn_amd
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
-    return megacrn_amd
+    megacrn_amd._lib.set_precision(request.param)
+    megacrn_amd.test_precision = megacrn_amd._lib.PRECISIONS[request.param]
+    yield megacrn_amd
+    megacrn_amd._lib.set_precision(megacrn_amd._lib.default_precision())
 
 
 def dev(a):
@@ -51,7 +57,8 @@ def test_gemm(amd, M, N, K, tA, tB, ns):
                             None if slabs is None else slabs.data_ptr(), torch.cuda.current_stream().cuda_stream),
           "gemm")
     torch.cuda.synchronize()
-    assert relerr(dC.cpu().numpy(), ref) < 2e-6 * max(1, np.sqrt(K) / 8)
+    tol = 2e-6 * max(1, np.sqrt(K) / 8) if amd.test_precision == 0 else 3e-5
+    assert relerr(dC.cpu().numpy(), ref) < tol
 
 
 # ------------------------------------------------------------------------------------------------
@@ -133,6 +140,7 @@ def build(amd, P, m):
                         num_layers=m["num_layers"], cheb_k=m["cheb_k"], mem_num=m["M"], mem_dim=m["D"],
                         cl_decay_steps=m["cl_decay"])
     model.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in P.items()})
+    model.precision = amd.test_precision
     return model.cuda()
 
 
@@ -250,6 +258,24 @@ def test_flat_clip_adam(amd):
         torch.cuda.synchronize()
         assert abs(tn.item() - gn) / gn < 1e-5
         assert relerr(tp.cpu().numpy(), P["w"]) < 1e-5
+
+
+def test_trainer_matches_oracle_trajectory(amd):
+    """FlatTrainer (forward, loss, backward into the flat bucket, fused clip+Adam) against the
+    reference's own 3-step loss trajectory (tests/golden, `odd` case)."""
+    from megacrn_amd.trainer import FlatTrainer
+    rec, P, m = load_case("odd", "f32")
+    model = build(amd, P, m).train()
+    flags = [[bool(v) for v in row] for row in rec["traj:teacher"]]
+    it = iter(flags)
+    model._teacher_flags = lambda labels, bs: next(it)
+    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+    x, ycov, y = dev(rec["x"]), dev(rec["ycov"]), dev(rec["labels"])
+    got = [tr.train_step(x, ycov, y).item() for _ in range(3)]
+    np.testing.assert_allclose(got, rec["traj:loss"], rtol=2e-4)
+    # parameters stayed ordinary nn.Parameters with the reference keys (views into the flat bucket)
+    assert list(model.state_dict().keys()) == list(P.keys())
+    assert abs(tr.total_norm.item() - 0) > 0
 
 
 def test_errors_are_loud(amd):
