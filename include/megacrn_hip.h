@@ -169,6 +169,13 @@ int mcrn_last_launch_count(void);
  * mcrn_prof_end synchronises on the recorded events and returns the summed kernel time, the number
  * of launches, their algorithmic flops (true channel counts) and executed flops. */
 int mcrn_prof_begin(int role);
+/* One-off tile autotuning for a model shape: runs a scratch forward+backward in which every distinct
+ * GEMM signature is timed once per tile configuration (HIP events) and the winner cached for all
+ * later calls in this process.  The only entry point that synchronises and allocates (temporaries,
+ * freed before return); call it outside the training loop.  `ws` is clobbered. */
+int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream);
+int mcrn_autotune_entries(void);
+int mcrn_autotune_clear(void);
 /* tuning hook: force GEMM tile configuration 0..6 for every launch (-1 = automatic) */
 int mcrn_set_gemm_cfg(int cfg);
 int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);

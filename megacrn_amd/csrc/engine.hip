@@ -14,10 +14,12 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <map>
 
 #include "../../include/megacrn_hip.h"
 #include "gemm_f32.h"
 #include "gemm_bf16x3.h"
+#include "prop_small.h"
 #include "ops.h"
 
 namespace mcrn {
@@ -65,6 +67,28 @@ struct Prof {
 };
 static Prof g_prof;
 
+// ---- tile-configuration autotuner --------------------------------------------------------------
+// The analytic cost model in choose_cfg() is only a prior: on shapes this small the best tile is
+// decided by latency / occupancy effects it cannot see (measured spread 2x).  In tuning mode
+// (mcrn_model_autotune) every distinct GEMM signature is timed once per configuration with HIP
+// events on scratch data and the winner is cached; later launches look it up.
+struct TuneKey {
+    int role, M, N, K, nbatch, akc, bkc, prec, split;
+    bool operator<(const TuneKey& o) const {
+        return memcmp(this, &o, sizeof(TuneKey)) < 0;
+    }
+};
+static std::map<TuneKey, int> g_tuned;
+static bool g_tuning = false;
+static hipEvent_t g_tune_ev[2];
+static bool g_tune_ev_ok = false;
+
+static inline int launch_any(GemmP& p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
+    if (g_precision == MCRN_BF16X3) CK(launch_gemm_x3(p, akc, bkc, max_split, role, st));
+    else CK(launch_gemm_f32(p, akc, bkc, max_split, st));
+    return 0;
+}
+
 static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
     if (!p.nbatch) p.nbatch = 1;
     for (int b = 0; b < 2; ++b) {   // per-batch hi strides default to the Dim2 value
@@ -72,10 +96,40 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
         if (!p.bk_hi[b]) p.bk_hi[b] = p.bk.hi;
     }
     ++g_launches;
+    const TuneKey key{role, p.M, p.N, p.K, p.nbatch, (int)akc, (int)bkc, g_precision, max_split};
+    const int saved_force = g_force_cfg;
+    if (g_force_cfg < 0) {
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) {
+            g_force_cfg = it->second;
+        } else if (g_tuning) {
+            if (!g_tune_ev_ok) {
+                CK(hipEventCreate(&g_tune_ev[0]));
+                CK(hipEventCreate(&g_tune_ev[1]));
+                g_tune_ev_ok = true;
+            }
+            int best = -1;
+            float best_ms = 1e30f;
+            for (int c = 0; c < NCFG; ++c) {
+                g_force_cfg = c;
+                CKI(launch_any(p, akc, bkc, max_split, role, st));            // warm-up
+                CK(hipEventRecord(g_tune_ev[0], st));
+                for (int r = 0; r < 3; ++r) CKI(launch_any(p, akc, bkc, max_split, role, st));
+                CK(hipEventRecord(g_tune_ev[1], st));
+                CK(hipEventSynchronize(g_tune_ev[1]));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                if (ms < best_ms) { best_ms = ms; best = c; }
+            }
+            g_tuned[key] = best;
+            g_force_cfg = best;
+        }
+    }
     const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
     if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
-    if (g_precision == MCRN_BF16X3) CK(launch_gemm_x3(p, akc, bkc, max_split, role, st));
-    else CK(launch_gemm_f32(p, akc, bkc, max_split, st));
+    const int rc_ = launch_any(p, akc, bkc, max_split, role, st);
+    g_force_cfg = saved_force;
+    if (rc_) return rc_;
     if (prof) {
         CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
         const double ex = 2.0 * p.M * p.N * (double)p.K * p.nbatch;
@@ -86,6 +140,21 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
     return 0;
 }
 
+// adjacency-stationary propagation (prop_small.h) with the same profiling hooks as gemm()
+static inline int prop_small(const PropP& p, int nbatch, int role, hipStream_t st) {
+    ++g_launches;
+    const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
+    if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    CK(launch_prop_small(p, nbatch, st));
+    if (prof) {
+        CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+        const double ex = 2.0 * p.N * (double)p.N * p.ncols * nbatch * p.nseg;
+        g_prof.exec_flops += ex;
+        g_prof.alg_flops += ex;
+        ++g_prof.n;
+    }
+    return 0;
+}
 // ---- bump allocator over the caller's workspace -------------------------------------------
 struct Bump {
     char* base;
@@ -119,6 +188,8 @@ static Shp mk_shape(int B, int N, int d, int H, int K) {
 struct Sup {   // the two supports, their transposes, and the slabbed gradient accumulators
     const float* S[2];
     const float* St[2];
+    const uint4* Sf[2];     // fragment-ordered bf16 hi/lo split of S (prop_small.h), or nullptr
+    const uint4* Stf[2];    // same for S^T
     long long ldS;
     float* dS;      // [2][nslab][N*ldS]
     int nslab;
@@ -126,6 +197,11 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
 };
 static int nslab_S(int N) { return N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1)); }
 static const int NSLAB_W = 64;
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline bool use_prop_small(const Sup& u, const Shp& s) {
+    return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && prop_small_ok(s.N, s.ld, (int)s.ld);
+}
 
 static GemmP gp() {
     GemmP p;
@@ -138,6 +214,19 @@ static GemmP gp() {
 
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
+    if (use_prop_small(u, s) && aligned16(Z)) {
+        PropP q;
+        memset(&q, 0, sizeof q);
+        q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f;
+        for (int b = 0; b < 2; ++b) { q.Sf[b][0] = u.Sf[b]; q.X[b][0] = Z; q.C[b] = Z + (1 + b * (s.K - 1)) * s.PS; }
+        CKI(prop_small(q, 2, ROLE_PROP, st));
+        if (s.K == 3) {   // x2 = 2 S x1 - x0
+            for (int b = 0; b < 2; ++b) { q.X[b][0] = Z + (1 + 2 * b) * s.PS; q.C[b] = Z + (2 + 2 * b) * s.PS; q.Cin[b] = Z; }
+            q.alpha = 2.f; q.beta = -1.f;
+            CKI(prop_small(q, 2, ROLE_PROP, st));
+        }
+        return 0;
+    }
     GemmP p = gp();
     p.M = s.N; p.N = (int)s.ld; p.K = s.N;
     p.am = plain(u.ldS); p.ak = plain(1);
@@ -187,7 +276,17 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
     }
-    if (s.K == 3) {   // d1 += S^T e2     (e2 = 2 d2, folded into Wd)
+    const bool small = use_prop_small(u, s) && aligned16(dP);
+    if (s.K == 3 && small) {
+        PropP q;
+        memset(&q, 0, sizeof q);
+        q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
+        for (int b = 0; b < 2; ++b) {
+            q.Sf[b][0] = u.Stf[b]; q.X[b][0] = dP + (2 + 2 * b) * s.PS;
+            q.C[b] = dP + (1 + 2 * b) * s.PS; q.Cin[b] = q.C[b];
+        }
+        CKI(prop_small(q, 2, ROLE_PROPT, st));
+    } else if (s.K == 3) {   // d1 += S^T e2     (e2 = 2 d2, folded into Wd)
         GemmP p = gp();
         p.M = s.N; p.N = (int)s.ld; p.K = s.N;
         p.am = plain(u.ldS); p.ak = plain(1);
@@ -219,7 +318,15 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
     }
-    {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b
+    if (small) {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b : two K-segments into one accumulator
+        PropP q;
+        memset(&q, 0, sizeof q);
+        q.nseg = 2; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
+        q.Sf[0][0] = u.Stf[0]; q.Sf[0][1] = u.Stf[1];
+        q.X[0][0] = dP + s.PS; q.X[0][1] = dP + (long long)(1 + (s.K - 1)) * s.PS;
+        q.C[0] = dP; q.Cin[0] = dP;
+        CKI(prop_small(q, 1, ROLE_PROPT, st));
+    } else {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b
         GemmP p = gp();
         p.M = s.N; p.N = (int)s.ld; p.K = 2 * s.N;
         p.A[0] = u.St[0]; p.am = plain(u.ldS);
@@ -246,15 +353,15 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
     return gemm(p, false, false, NSLAB_W, ROLE_WGRAD, st);
 }
 
+static const int COLSUM_CHUNK = 512;
 static int colsum(const float* X, long long ld, long long rows, int C, float* part, float* out,
                   int accumulate, hipStream_t st) {
-    const int chunk = 256;
-    int nblk = cdiv(rows, chunk);
-    LAUNCH(k_colsum_stage1, dim3(nblk), dim3(256), 0, st, X, ld, rows, C, chunk, part);
-    LAUNCH(k_colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)part, nblk, C, out, accumulate);
+    const int nchunk = cdiv(rows, COLSUM_CHUNK);
+    LAUNCH(k_colsum_stage1, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, X, ld, rows, C, COLSUM_CHUNK, part);
+    LAUNCH(k_colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, (const float*)part, nchunk, C, out, accumulate);
     return 0;
 }
-static size_t colsum_part_floats(long long rows, int C) { return (size_t)cdiv(rows, 256) * C; }
+static size_t colsum_part_floats(long long rows, int C) { return (size_t)cdiv(rows, COLSUM_CHUNK) * C; }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
 struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; };
@@ -287,7 +394,7 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
 }
 
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
-struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; };
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; uint4* frag[4]; };
 static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
     o.ldS = ldS;
@@ -297,11 +404,21 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     o.St1 = b.take<float>(nn); o.St2 = b.take<float>(nn);
     o.dLa = b.take<float>(nn); o.dLb = b.take<float>(nn); o.dLs = b.take<float>(nn);
     o.dE1 = b.take<float>(nd); o.dE2 = b.take<float>(nd);
+    for (int i = 0; i < 4; ++i) o.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
 }
 static int transpose(float* dst, long long ldd, const float* src, long long lds_, const float* add,
                      long long lda, int N, hipStream_t st) {
     dim3 g(cdiv(N, 32), cdiv(N, 32));
     LAUNCH(k_transpose_add, g, dim3(256), 0, st, dst, ldd, src, lds_, add, lda, N);
+    return 0;
+}
+// fragment-ordered bf16 hi/lo images of S1, S2, S1^T, S2^T for the adjacency-stationary kernels
+static int build_frags(const float* s1, const float* s2, long long ld, int N, uint4* const* frag, hipStream_t st) {
+    if (!frag[0] || N > 256) return 0;
+    ++g_launches; CK(launch_sfrag(s1, ld, N, 0, frag[0], st));
+    ++g_launches; CK(launch_sfrag(s2, ld, N, 0, frag[1], st));
+    ++g_launches; CK(launch_sfrag(s1, ld, N, 1, frag[2], st));
+    ++g_launches; CK(launch_sfrag(s2, ld, N, 1, frag[3], st));
     return 0;
 }
 static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
@@ -328,6 +445,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
     if (want_T) {
         CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
         CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
+        CKI(build_frags(g1, g2, ldg, N, o.frag, st));
     }
     return 0;
 }
@@ -492,6 +610,7 @@ static Sup model_sup(const ModelPlan& P, int N) {
     Sup u;
     u.S[0] = P.sup.g1; u.S[1] = P.sup.g2;
     u.St[0] = P.sup.St1; u.St[1] = P.sup.St2;
+    u.Sf[0] = P.sup.frag[0]; u.Sf[1] = P.sup.frag[1]; u.Stf[0] = P.sup.frag[2]; u.Stf[1] = P.sup.frag[3];
     u.ldS = P.ldS;
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
     return u;
@@ -693,6 +812,7 @@ struct CellPlan {
     float *Z, *Y, *zr, *hc, *hn_rows;
     float *Wf[2], *Wd[2], *dWs[2];
     float *St1, *St2, *dS;
+    uint4* frag[4];
     int nslabS;
     float *dP, *dQ, *dU, *dG, *dacc, *dxin, *part;
     size_t total;
@@ -710,6 +830,7 @@ static void plan_cell(int B, int N, int din, int H, int K, char* base, CellPlan&
         P.Wf[i] = b.take<float>(n); P.Wd[i] = b.take<float>(n); P.dWs[i] = b.take<float>(n * NSLAB_W);
     }
     P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
+    for (int i = 0; i < 4; ++i) P.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     P.nslabS = nslab_S(N);
     P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
     P.dP = b.take<float>((size_t)s.ZT); P.dQ = b.take<float>((size_t)s.ZT);
@@ -732,6 +853,7 @@ static int rows_to_bnc(float* dst, const float* src, long long ld, int col0, int
 struct AgcnPlan {
     Shp s;
     float *Z, *y_rows, *Wf, *Wd, *dWs, *St1, *St2, *dS, *dP, *dY, *part;
+    uint4* frag[4];
     int nslabS;
     size_t total;
 };
@@ -744,6 +866,7 @@ static void plan_agcn(int B, int N, int C, int O, int K, char* base, AgcnPlan& P
     size_t n = (size_t)s.G * s.Cp * O;
     P.Wf = b.take<float>(n); P.Wd = b.take<float>(n); P.dWs = b.take<float>(n * NSLAB_W);
     P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
+    for (int i = 0; i < 4; ++i) P.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     P.nslabS = nslab_S(N);
     P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
     P.dP = b.take<float>((size_t)s.ZT);
@@ -782,6 +905,53 @@ int mcrn_version(void) { return 100; }
 int mcrn_last_launch_count(void) { return g_launches; }
 
 int mcrn_set_gemm_cfg(int cfg) { g_force_cfg = cfg; return 0; }
+
+int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream) {
+    CKI(check_dims(d));
+    if (!ws || ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("autotune: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    // scratch parameters / inputs / outputs carved from the END of nothing: allocate temporaries here
+    // (this entry point is the one place that may allocate: it runs once per shape, outside any step)
+    const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num, K = d->cheb_k;
+    const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim, din = d->input_dim;
+    const size_t Ce = din + H, Cd = od + yd + Hd;
+    const size_t np[14] = {(size_t)M * D, (size_t)H * D, (size_t)N * M, (size_t)N * M,
+                           2 * K * Ce * 2 * H, (size_t)2 * H, 2 * K * Ce * H, (size_t)H,
+                           2 * K * Cd * 2 * Hd, (size_t)2 * Hd, 2 * K * Cd * Hd, (size_t)Hd,
+                           (size_t)od * Hd, (size_t)od};
+    size_t tot = 0;
+    for (int i = 0; i < 14; ++i) tot += (np[i] + 63) / 64 * 64;
+    const size_t nx = (size_t)B * d->T_in * N * din, nyc = (size_t)B * d->T_out * N * (yd > 0 ? yd : 1),
+                 nout = (size_t)B * d->T_out * N * od, nbd = (size_t)B * N * D;
+    float* buf = nullptr;
+    const size_t nfl = 2 * tot + nx + nyc + 2 * nout + 5 * nbd;
+    CK(hipMalloc(&buf, nfl * sizeof(float)));
+    CK(hipMemsetAsync(buf, 0, nfl * sizeof(float), st));
+    float* q = buf;
+    const float* pp[14];
+    float* gg[14];
+    for (int i = 0; i < 14; ++i) { pp[i] = q; q += (np[i] + 63) / 64 * 64; }
+    for (int i = 0; i < 14; ++i) { gg[i] = q; q += (np[i] + 63) / 64 * 64; }
+    float* x = q; q += nx;
+    float* yc = q; q += nyc;
+    float* out = q; q += nout;
+    float* dout = q; q += nout;
+    float* o4[4];
+    for (int i = 0; i < 4; ++i) { o4[i] = q; q += nbd; }
+    float* dq = q; q += nbd;
+    mcrn_params_t P = {pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], pp[9], pp[10], pp[11], pp[12], pp[13]};
+    mcrn_grads_t G = {gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9], gg[10], gg[11], gg[12], gg[13]};
+    g_precision = d->precision;
+    g_tuning = true;
+    int rc = model_forward(d, &P, x, yc, nullptr, nullptr, (char*)ws, out, o4[0], o4[1], o4[2], o4[3], st);
+    if (!rc) rc = model_backward(d, &P, nullptr, dout, nullptr, dq, nullptr, nullptr, (char*)ws, &G, st);
+    g_tuning = false;
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    return rc;
+}
+int mcrn_autotune_entries(void) { return (int)g_tuned.size(); }
+int mcrn_autotune_clear(void) { g_tuned.clear(); return 0; }
 int mcrn_set_precision(int precision) {
     if (precision != MCRN_F32 && precision != MCRN_BF16X3) FAIL("unsupported precision %d", precision);
     g_precision = precision;
@@ -892,8 +1062,9 @@ int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, co
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
     CKI(wprep(W, P.Wf, P.Wd, s, O, st));
+    CKI(build_frags(s1, s2, N, N, P.frag, st));
     CKI(bnc_to_rows(P.Z, s.Cp, 0, C, x, B, N, st));
     CKI(zero_cols(P.Z, 0, s.Cp, s.C, s.Cp, s.R, 1, st));
     CKI(prop_fwd(s, u, P.Z, st));
@@ -911,7 +1082,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
@@ -944,9 +1115,10 @@ int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, 
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
     CKI(wprep(gate_w, P.Wf[0], P.Wd[0], s, 2 * H, st));
     CKI(wprep(update_w, P.Wf[1], P.Wd[1], s, H, st));
+    CKI(build_frags(s1, s2, N, N, P.frag, st));
     CKI(bnc_to_rows(P.Z, s.Cp, 0, H, h, B, N, st));
     CKI(bnc_to_rows(P.Z, s.Cp, H, din, x, B, N, st));
     CKI(bnc_to_rows(P.Y, s.Cp, H, din, x, B, N, st));
@@ -967,7 +1139,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));

@@ -43,60 +43,94 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
 }
 
 // ---- operand tile: E rows x 32 k ; thread owns NP (row, k-group-of-8) pairs -------------------
+// Fast path (host-verified, see fast_ok): no divisions, no bounds branches inside the K loop.
+//   rows are clamped to the last valid row (their results are never stored), per-thread pointers
+//   advance by 32 k per tile with an incremental wrap for two-level k maps.
+//   KC: two float4 units per pair (each 16-B aligned, never straddling `inner`);
+//   RC: 8 dwords k..k+7 of one row (coalesced across lanes), never straddling `inner`.
+// Slow path: fully general per-element address map + bounds (K-tail tile, odd strides).
 template <int E, bool KC>
 struct TileX {
     static constexpr int NP = (E * 4 + 255) / 256;
+    static constexpr int NU = KC ? 2 : 1;       // independently tracked units per pair
     static constexpr int SZ = E * 5;            // uint4 per image (80-byte rows)
+    const float* ptr[NP][NU];
+    int rem[NP][NU];
     long long roff[NP];
     int row[NP], kg[NP];
     float v[NP][8];
 
-    __device__ __forceinline__ void init_rows(int tid, int row0, int nrows, const Dim2& d) {
+    __device__ __forceinline__ void init(const float* __restrict__ base, int tid, int row0, int nrows,
+                                         const Dim2& d, int kbeg, int kinner, long long khi, long long klo) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int pi = tid + 256 * q;
             int r, g;
             if (KC) { r = pi >> 2; g = pi & 3; } else { r = pi % E; g = pi / E; }
+            if (r >= E) { r = E - 1; }
+            if (g > 3) g = 3;
             row[q] = r; kg[q] = g;
-            const int gr = row0 + r;
-            roff[q] = (pi < E * 4 && gr < nrows) ? d2off(d.inner, d.hi, d.lo, gr) : -1;
+            int gr = row0 + r;
+            const bool valid = gr < nrows;
+            if (!valid) gr = nrows - 1;                       // clamp: finite data, result discarded
+            const long long ro = d2off(d.inner, d.hi, d.lo, gr);
+            roff[q] = valid ? ro : -1;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int k = kbeg + 8 * g + 4 * u;
+                int qd = 0, rm = k;
+                if (kinner > 0) { qd = k / kinner; rm = k - qd * kinner; }
+                ptr[q][u] = base + ro + (long long)qd * khi + (long long)rm * klo;
+                rem[q][u] = rm;
+            }
         }
     }
-    __device__ __forceinline__ void load(const float* __restrict__ base, int k0, int kend, int kinner,
-                                         long long khi, long long klo, bool vec) {
+    __device__ __forceinline__ void advance(int kinner, long long khi, long long klo) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                ptr[q][u] += 32 * klo;
+                if (kinner > 0) {
+                    rem[q][u] += 32;
+                    while (rem[q][u] >= kinner) { rem[q][u] -= kinner; ptr[q][u] += khi - (long long)kinner * klo; }
+                }
+            }
+    }
+    // full tile, fast path: the pointers already address this tile
+    __device__ __forceinline__ void load_fast(long long klo) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (KC) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 t = *reinterpret_cast<const float4*>(ptr[q][u]);
+                    v[q][4 * u] = t.x; v[q][4 * u + 1] = t.y; v[q][4 * u + 2] = t.z; v[q][4 * u + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[q][j] = ptr[q][0][(long long)j * klo];
+            }
+        }
+    }
+    // any tile, general path (one division per group + bounds); independent of the incremental pointers
+    __device__ __forceinline__ void load_slow(const float* __restrict__ base, int k0, int kend, int kinner,
+                                              long long khi, long long klo) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int k = k0 + 8 * kg[q];
-            if (roff[q] < 0 || k >= kend) {
+            const bool rv = roff[q] >= 0;
+            const float* __restrict__ rp = base + (rv ? roff[q] : 0);
+            int kc = k < kend ? k : kend - 1;                 // clamp, then mask: no OOB address is formed
+            int qd = 0, rm = kc;
+            if (kinner > 0) { qd = kc / kinner; rm = kc - qd * kinner; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[q][j] = 0.f;
-                continue;
-            }
-            const float* __restrict__ rp = base + roff[q];
-            if (KC) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int kk = k + 4 * h;
-                    if (vec && kk + 3 < kend) {        // 4 consecutive k are contiguous and 16-B aligned
-                        const float4 t = *reinterpret_cast<const float4*>(rp + d2off(kinner, khi, klo, kk));
-                        v[q][4 * h] = t.x; v[q][4 * h + 1] = t.y; v[q][4 * h + 2] = t.z; v[q][4 * h + 3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[q][4 * h + j] = (kk + j < kend) ? rp[d2off(kinner, khi, klo, kk + j)] : 0.f;
-                    }
-                }
-            } else {
-                if (kinner <= 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[q][j] = (k + j < kend) ? rp[(long long)(k + j) * klo] : 0.f;
-                } else {
-                    int qd = k / kinner, rm = k - qd * kinner;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        v[q][j] = (k + j < kend) ? rp[(long long)qd * khi + (long long)rm * klo] : 0.f;
-                        if (++rm == kinner) { rm = 0; ++qd; }
-                    }
+            for (int j = 0; j < 8; ++j) {
+                const float x = rp[(long long)qd * khi + (long long)rm * klo];
+                v[q][j] = (rv && k + j < kend) ? x : 0.f;
+                if (k + j + 1 < kend) {                       // advance to the next valid k only
+                    ++rm;
+                    if (kinner > 0 && rm == kinner) { rm = 0; ++qd; }
                 }
             }
         }
@@ -142,12 +176,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const float* __restrict__ Ab = p.A[batch];
     const float* __restrict__ Bb = p.B[batch];
     const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
-    const bool avec = (p.vec & 1) != 0, bvec = (p.vec & 2) != 0;
+    const bool afast = (p.vec & 1) != 0, bfast = (p.vec & 2) != 0;
 
     TA ta;
     TB tb;
-    ta.init_rows(tid, m_blk, p.M, p.am);
-    tb.init_rows(tid, n_blk, p.N, p.bn);
+    ta.init(Ab, tid, m_blk, p.M, p.am, kbeg, p.ak.inner, akhi, p.ak.lo);
+    tb.init(Bb, tid, n_blk, p.N, p.bn, kbeg, p.bk.inner, bkhi, p.bk.lo);
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -157,8 +191,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    ta.load(Ab, kbeg, kend, p.ak.inner, akhi, p.ak.lo, avec);
-    tb.load(Bb, kbeg, kend, p.bk.inner, bkhi, p.bk.lo, bvec);
+    // tiles [kbeg, kfull) are complete (32 valid k); the last one may be a partial tail
+    const int kfull = kbeg + ((kend - kbeg) & ~31);
+#define MCRN_LOAD_TILE(K0)                                                                   \
+    do {                                                                                     \
+        const bool full_ = (K0) < kfull;                                                     \
+        if (afast && full_) ta.load_fast(p.ak.lo); else ta.load_slow(Ab, (K0), kend, p.ak.inner, akhi, p.ak.lo); \
+        if (bfast && full_) tb.load_fast(p.bk.lo); else tb.load_slow(Bb, (K0), kend, p.bk.inner, bkhi, p.bk.lo); \
+    } while (0)
+    MCRN_LOAD_TILE(kbeg);
     ta.store(sAh, sAl, tid);
     tb.store(sBh, sBl, tid);
     __syncthreads();
@@ -167,8 +208,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         const bool more = k0 + 32 < kend;
         if (more) {
-            ta.load(Ab, k0 + 32, kend, p.ak.inner, akhi, p.ak.lo, avec);
-            tb.load(Bb, k0 + 32, kend, p.bk.inner, bkhi, p.bk.lo, bvec);
+            if (afast) ta.advance(p.ak.inner, akhi, p.ak.lo);
+            if (bfast) tb.advance(p.bk.inner, bkhi, p.bk.lo);
+            MCRN_LOAD_TILE(k0 + 32);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -201,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
             __syncthreads();
         }
     }
+#undef MCRN_LOAD_TILE
     gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kq, n_blk + wn * WN + l31);
 }
 
@@ -218,7 +261,9 @@ static inline hipError_t launch_cfg_x3(const GemmP& p, int cfg, hipStream_t st) 
         case 1: return launch_one_x3<64, 128, 2, 2, AKC, BKC, ROLE>(p, st);
         case 2: return launch_one_x3<128, 64, 2, 2, AKC, BKC, ROLE>(p, st);
         case 3: return launch_one_x3<64, 64, 2, 2, AKC, BKC, ROLE>(p, st);
-        default: return launch_one_x3<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
+        case 4: return launch_one_x3<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
+        case 5: return launch_one_x3<256, 64, 4, 1, AKC, BKC, ROLE>(p, st);
+        default: return launch_one_x3<64, 256, 1, 4, AKC, BKC, ROLE>(p, st);
     }
 }
 static inline hipError_t launch_role_x3(const GemmP& p, bool akc, bool bkc, int role, int cfg, hipStream_t st) {
@@ -235,10 +280,12 @@ static inline hipError_t launch_role_x3(const GemmP& p, bool akc, bool bkc, int 
     return launch_cfg_x3<false, true, ROLE_MISC>(p, cfg, st);
 }
 
-// float4 eligibility of a K-contiguous operand: unit k stride, every 4-group of k (k % 4 == 0)
-// contiguous and 16-byte aligned for every row of every batch.
-static inline bool vec_ok(const float* const* bases, int nbatch, const Dim2& rows, const Dim2& k,
-                          const long long* khi) {
+// Fast-path eligibility of an operand (see TileX).  K-contiguous: unit k stride, every aligned
+// 4-group of k contiguous and 16-byte aligned for every row of every batch.  Row-contiguous: an
+// aligned 8-group of k never straddles the inner extent of a two-level k map.
+static inline bool fast_ok(bool kc, const float* const* bases, int nbatch, const Dim2& rows, const Dim2& k,
+                           const long long* khi) {
+    if (!kc) return k.inner <= 0 || (k.inner % 8) == 0;
     if (k.lo != 1) return false;
     for (int b = 0; b < nbatch; ++b) {
         if (((uintptr_t)bases[b]) & 15) return false;
@@ -254,8 +301,8 @@ static inline hipError_t launch_gemm_x3(GemmP p, bool akc, bool bkc, int max_spl
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     const int cfg = choose_cfg(p, max_split, 32);
     p.vec = 0;
-    if (akc && vec_ok(p.A, p.nbatch, p.am, p.ak, p.ak_hi)) p.vec |= 1;
-    if (bkc && vec_ok(p.B, p.nbatch, p.bn, p.bk, p.bk_hi)) p.vec |= 2;
+    if (fast_ok(akc, p.A, p.nbatch, p.am, p.ak, p.ak_hi)) p.vec |= 1;
+    if (fast_ok(bkc, p.B, p.nbatch, p.bn, p.bk, p.bk_hi)) p.vec |= 2;
     return launch_role_x3(p, akc, bkc, role, cfg, st);
 }
 

@@ -86,6 +86,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                  \
         const int c = c_base + j * 32;                                                 \
         if (c < p.N) {                                                                 \
+            const long long co = d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);               \
+            (void)co;                                                                  \
             _Pragma("unroll") for (int i = 0; i < FM; ++i) {                          \
                 _Pragma("unroll") for (int v = 0; v < 16; ++v) {                      \
                     const int r = r_base + i * 32 + (v & 3) + 8 * (v >> 2);            \
@@ -100,18 +102,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     if (p.epi == EPI_STORE) {
         if (Cin) {
             MCRN_EPI_LOOP({
-                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
                 Cb[off] = p.alpha * a + p.beta * Cin[off];
             })
         } else {
             MCRN_EPI_LOOP({
-                const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+                const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
                 Cb[off] = p.alpha * a;
             })
         }
     } else if (p.epi == EPI_BIAS) {
         MCRN_EPI_LOOP({
-            const long long off = d2off(p.cm.inner, p.cm.hi, p.cm.lo, r) + d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);
+            const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
             Cb[off] = a + p.bias[c];
         })
     } else if (p.epi == EPI_GATE) {
@@ -286,9 +288,9 @@ static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     return hipGetLastError();
 }
 // tile configurations: {BM, BN, waves in M, waves in N}
-static const int NCFG = 5;
+static const int NCFG = 7;
 static const int kCfg[NCFG][4] = {{128, 128, 2, 2}, {64, 128, 2, 2}, {128, 64, 2, 2}, {64, 64, 2, 2},
-                                  {32, 128, 1, 4}};
+                                  {32, 128, 1, 4},  {256, 64, 4, 1}, {64, 256, 1, 4}};
 template <bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_cfg(const GemmP& p, int cfg, hipStream_t st) {
     switch (cfg) {
@@ -296,7 +298,9 @@ static inline hipError_t launch_cfg(const GemmP& p, int cfg, hipStream_t st) {
         case 1: return launch_one<64, 128, 2, 2, AKC, BKC, ROLE>(p, st);
         case 2: return launch_one<128, 64, 2, 2, AKC, BKC, ROLE>(p, st);
         case 3: return launch_one<64, 64, 2, 2, AKC, BKC, ROLE>(p, st);
-        default: return launch_one<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
+        case 4: return launch_one<32, 128, 1, 4, AKC, BKC, ROLE>(p, st);
+        case 5: return launch_one<256, 64, 4, 1, AKC, BKC, ROLE>(p, st);
+        default: return launch_one<64, 256, 1, 4, AKC, BKC, ROLE>(p, st);
     }
 }
 static inline hipError_t launch_f32(const GemmP& p, bool akc, bool bkc, int cfg, hipStream_t st) {
@@ -310,13 +314,20 @@ static inline hipError_t launch_f32(const GemmP& p, bool akc, bool bkc, int cfg,
 // number of slabs the caller provisioned behind C (stride p.slab).  kgran = K-tile depth.
 static inline int choose_cfg(GemmP& p, int max_split, int kgran) {
     if (p.nbatch <= 0) p.nbatch = 1;
-    static const double eff[NCFG] = {1.00, 0.92, 0.92, 0.85, 0.80};
+    // Cost model (seconds): the larger of
+    //   matrix-core time  : ceil(workgroups / 256 CUs) * tile MACs / per-CU rate
+    //   operand traffic   : A is re-read once per N-tile, B once per M-tile (operands > one XCD L2
+    //                       come from MALL/HBM at ~4.5 TB/s, small ones from L2 at ~20 TB/s) + C
+    // plus a fixed per-K-tile latency term for the un-overlapped part of the pipeline.
+    const double cu_rate = (kgran == 32 ? 1365.0 : 256.0) * 2.2e9;     // flop/s per CU (bf16x3 / f32)
     int best = 3, best_split = 1;
     double best_t = 1e300;
+    const double Abytes = 4.0 * p.M * (double)p.K * p.nbatch, Bbytes = 4.0 * p.N * (double)p.K * p.nbatch;
     for (int i = 0; i < NCFG; ++i) {
         if (g_force_cfg >= 0 && i != g_force_cfg) continue;
         const int bm = kCfg[i][0], bn = kCfg[i][1];
-        const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch;
+        const long long tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+        const long long tiles = tm * tn * p.nbatch;
         int ns = 1;
         if (max_split > 1) {
             ns = (int)((512 + tiles - 1) / tiles);
@@ -326,10 +337,13 @@ static inline int choose_cfg(GemmP& p, int max_split, int kgran) {
             if (ns > maxk) ns = maxk;
             if (ns < 1) ns = 1;
         }
-        // MFMA-bound model: a CU retires one workgroup-tile per (bm*bn*K) MFMA cycles regardless of
-        // how many are resident, so time ~ ceil(tiles / 256 CUs) * tile work (+ fixed per-tile cost)
+        const double kc = (double)p.K / ns;
         const double rounds = ceil((double)tiles * ns / 256.0);
-        const double t = rounds * ((double)bm * bn * ((double)p.K / ns) + 6000.0 * 16) / eff[i];
+        const double t_mma = rounds * (2.0 * bm * bn * kc) / cu_rate;
+        const double bwA = Abytes < 2.0e6 ? 20e12 : 4.5e12, bwB = Bbytes < 2.0e6 ? 20e12 : 4.5e12;
+        const double t_mem = Abytes * tn / bwA + Bbytes * tm / bwB + 4.0 * p.M * (double)p.N * p.nbatch * ns * (p.Cin[0] ? 2 : 1) / 4.5e12;
+        const double t_lat = rounds * (kc / kgran) * 0.35e-6 + 2e-6;
+        const double t = (t_mma > t_mem ? t_mma : t_mem) + t_lat;
         if (t < best_t) { best_t = t; best = i; best_split = ns; }
     }
     int kchunk = ((p.K + best_split - 1) / best_split + kgran - 1) / kgran * kgran;

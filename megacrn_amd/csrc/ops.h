@@ -431,23 +431,37 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // deterministic column sums:  out[c] (+)= sum_r w[r]*X[r*ld + c]   (w nullable), two stages
 // ---------------------------------------------------------------------------------------------
+// grid (ceil(C/64), nchunk): 256 threads = 64 columns x 4 row lanes; rows of the chunk are strided over
+// the lanes, partial[chunk][c] written after an LDS reduction over the 4 lanes (fixed order).
 __global__ void k_colsum_stage1(const float* __restrict__ X, long long ld, long long rows, int C,
                                 int chunk, float* __restrict__ part) {
-    long long r0 = (long long)blockIdx.x * chunk;
-    long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += X[r * ld + c];
-        part[(long long)blockIdx.x * C + c] = s;
-    }
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long r0 = (long long)blockIdx.y * chunk;
+    const long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    float s = 0.f;
+    if (c < C)
+        for (long long r = r0 + rl; r < r1; r += 4) s += X[r * ld + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(long long)blockIdx.y * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
+// grid ceil(C/64): same 64 x 4 layout over the partial rows
 __global__ void k_colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ out,
                                 int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int b = rl; b < nblk; b += 4) s += part[(long long)b * C + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // out[i] = sum_z slabs[z*slab + i]

@@ -27,7 +27,7 @@ def masked_mae_loss(y_pred, y_true):
 
 class FlatTrainer:
     def __init__(self, model, *, lr=0.01, eps=1e-3, betas=(0.9, 0.999), max_grad_norm=5.0, lamb=0.01,
-                 lamb1=0.01, scaler_mean=0.0, scaler_std=1.0, process_group=None):
+                 lamb1=0.01, scaler_mean=0.0, scaler_std=1.0, process_group=None, autotune=True):
         if model.num_layers != 1:
             raise ValueError("FlatTrainer drives the fused num_layers==1 path")
         self.model = model
@@ -35,6 +35,7 @@ class FlatTrainer:
         self.lamb, self.lamb1 = lamb, lamb1
         self.mean, self.std = float(scaler_mean), float(scaler_std)
         self.group = process_group
+        self.autotune = autotune
         self.world = dp.world_size(process_group)
         params = list(model._fused_params())
         dev = params[0].device
@@ -80,6 +81,9 @@ class FlatTrainer:
                 raise ValueError(lib.mcrn_last_error().decode())
             dev = x.device
             self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            if self.autotune:      # once per shape: pick the fastest GEMM tile per signature on-device
+                check(lib.mcrn_model_autotune(C.byref(self.d), self._ws.data_ptr(), nb,
+                                              torch.cuda.current_stream().cuda_stream), "mcrn_model_autotune")
             B, N, To, od, D = self.d.B, self.d.N, self.d.T_out, self.d.output_dim, self.d.mem_dim
             self.out = torch.empty(B, To, N, od, device=dev)
             self.hatt, self.q, self.pos, self.neg = (torch.empty(B, N, D, device=dev) for _ in range(4))

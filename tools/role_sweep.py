@@ -22,7 +22,7 @@ torch.manual_seed(1234)
 model = megacrn_amd.MegaCRN(cfg["N"], 1, 1, cfg["T"], cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(dev).train()
 tr = FlatTrainer(model, scaler_mean=54.4, scaler_std=19.5)
 x, yc, y = bench.synth(cfg, B, 1234, dev)
-CFG = ["128x128", "64x128", "128x64", "64x64", "32x128", "32x256", "256x32", "auto"]
+CFG = ["128x128", "64x128", "128x64", "64x64", "32x128", "256x64", "64x256", "auto"]
 res = {}
 for c in list(range(7)) + [-1]:
     lib.mcrn_set_gemm_cfg(c)
