@@ -30,7 +30,7 @@ CONFIGS = {
     "syn8192": dict(N=8192, B=32, T=12, H=64, M=20, D=64, label="synthetic N=8192"),
 }
 SC_MEAN, SC_STD = 54.4, 19.5
-PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK = {"f32": 157.3e12, "bf16x3": 2500e12}   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
 ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
 
 
@@ -112,6 +112,7 @@ def main():
                                 rnn_units=cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(device).train()
     tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
     x, ycov, y = synth(cfg, B, 1234 + rank, device)
+    dtype = {0: "f32", 1: "bf16x3"}[model.precision]
 
     def sync_all():
         if world > 1:
@@ -156,9 +157,13 @@ def main():
         torch.cuda.synchronize()
         check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
         ach = af.value / (ms.value * 1e-3)
-        roof = {"bound": "mfma", "kernel": "mcrn::gemm_f32_kernel<..., ROLE=1> (K-hop propagation S x Z)",
-                "achieved": round(ach / 1e12, 3), "peak": round(PEAK_F32_MFMA / 1e12, 1), "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+        kname = ("mcrn::prop_small_kernel<NF>" if cfg["N"] <= 256 and dtype == "bf16x3" else
+                 "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
+        roof = {"bound": "mfma", "kernel": kname + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
+                "achieved": round(ach / 1e12, 3), "peak": round(PEAK[dtype] / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(ach / PEAK[dtype], 5), "traffic": None,
+                "note": "achieved = algorithmic fp32 flops (2 supports x 2 N^2 B C per launch) / HIP-event kernel time"
+                        + ("; bf16x3 issues 3 bf16 MFMAs per product, ceiling 833 TF" if dtype == "bf16x3" else ""),
                 "avg_launch_us": round(1e3 * ms.value / n.value, 3), "launches": n.value,
                 "alg_flops_per_launch": af.value / n.value}
         sync_all()
@@ -180,7 +185,7 @@ def main():
             "metric": "training samples/sec (12-step seq2seq)" if cfg["T"] == 12 else "training samples/sec (6-step seq2seq)",
             "value": round(val, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} "
                                    f"mem={cfg['M']}x{cfg['D']} cheb_k=3, per-GPU batch {B}, full train step "
                                    f"(fwd + 3-term loss + bwd + all-reduce + clip + Adam)",
