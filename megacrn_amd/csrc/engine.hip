@@ -141,18 +141,22 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
 }
 
 // adjacency-stationary propagation (prop_small.h) with the same profiling hooks as gemm()
-static inline int prop_small(const PropP& p, int nbatch, int role, hipStream_t st) {
-    ++g_launches;
-    const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
-    if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
-    CK(launch_prop_small(p, nbatch, st));
-    if (prof) {
-        CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
-        const double ex = 2.0 * p.N * (double)p.N * p.ncols * nbatch * p.nseg;
-        g_prof.exec_flops += ex;
-        g_prof.alg_flops += ex;
-        ++g_prof.n;
-    }
+#define MCRN_PROF_WRAP(ROLE, LAUNCH, EXEC, ALG)                                                \
+    do {                                                                                      \
+        ++g_launches;                                                                         \
+        const bool prof__ = g_prof.role == (ROLE) && g_prof.n < Prof::MAXEV;                  \
+        if (prof__) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));                          \
+        CK(LAUNCH);                                                                           \
+        if (prof__) {                                                                         \
+            CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));                              \
+            g_prof.exec_flops += (EXEC);                                                      \
+            g_prof.alg_flops += (ALG);                                                        \
+            ++g_prof.n;                                                                       \
+        }                                                                                     \
+    } while (0)
+static inline int prop_small(const PropP& p, int nbatch, int role, double alg, hipStream_t st) {
+    const double ex = 2.0 * p.N * (double)p.N * p.ncols * nbatch * p.nseg;
+    MCRN_PROF_WRAP(role, launch_prop_small(p, nbatch, st), ex, alg > 0 ? alg : ex);
     return 0;
 }
 // ---- bump allocator over the caller's workspace -------------------------------------------
@@ -214,16 +218,24 @@ static GemmP gp() {
 
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
+    if (use_prop_small(u, s) && aligned16(Z) && s.K == 3) {   // both hops, one launch
+        Prop2P q;
+        q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        const double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
+        const double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
+        MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), ex, alg);
+        return 0;
+    }
     if (use_prop_small(u, s) && aligned16(Z)) {
         PropP q;
         memset(&q, 0, sizeof q);
         q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f;
         for (int b = 0; b < 2; ++b) { q.Sf[b][0] = u.Sf[b]; q.X[b][0] = Z; q.C[b] = Z + (1 + b * (s.K - 1)) * s.PS; }
-        CKI(prop_small(q, 2, ROLE_PROP, st));
+        CKI(prop_small(q, 2, ROLE_PROP, 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st));
         if (s.K == 3) {   // x2 = 2 S x1 - x0
             for (int b = 0; b < 2; ++b) { q.X[b][0] = Z + (1 + 2 * b) * s.PS; q.C[b] = Z + (2 + 2 * b) * s.PS; q.Cin[b] = Z; }
             q.alpha = 2.f; q.beta = -1.f;
-            CKI(prop_small(q, 2, ROLE_PROP, st));
+            CKI(prop_small(q, 2, ROLE_PROP, 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st));
         }
         return 0;
     }
@@ -277,7 +289,15 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
-    if (s.K == 3 && small) {
+    const bool fused_bwd = small && s.K == 3;
+    if (fused_bwd) {
+        // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
+        // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
+        Prop2P q;
+        q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
+        MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
+    } else if (s.K == 3 && small) {
         PropP q;
         memset(&q, 0, sizeof q);
         q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
@@ -285,7 +305,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             q.Sf[b][0] = u.Stf[b]; q.X[b][0] = dP + (2 + 2 * b) * s.PS;
             q.C[b] = dP + (1 + 2 * b) * s.PS; q.Cin[b] = q.C[b];
         }
-        CKI(prop_small(q, 2, ROLE_PROPT, st));
+        CKI(prop_small(q, 2, ROLE_PROPT, 0, st));
     } else if (s.K == 3) {   // d1 += S^T e2     (e2 = 2 d2, folded into Wd)
         GemmP p = gp();
         p.M = s.N; p.N = (int)s.ld; p.K = s.N;
@@ -318,15 +338,17 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
     }
-    if (small) {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b : two K-segments into one accumulator
+    if (fused_bwd) {
+        // done above
+    } else if (small) {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b : two K-segments into one accumulator
         PropP q;
         memset(&q, 0, sizeof q);
         q.nseg = 2; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
         q.Sf[0][0] = u.Stf[0]; q.Sf[0][1] = u.Stf[1];
         q.X[0][0] = dP + s.PS; q.X[0][1] = dP + (long long)(1 + (s.K - 1)) * s.PS;
         q.C[0] = dP; q.Cin[0] = dP;
-        CKI(prop_small(q, 1, ROLE_PROPT, st));
-    } else {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b
+        CKI(prop_small(q, 1, ROLE_PROPT, 0, st));
+    } else if ((s.N & 3) == 0) {   // dx0 = dP[0] + [S1^T | S2^T] [d1t_a ; d1t_b] : one K-concatenated GEMM
         GemmP p = gp();
         p.M = s.N; p.N = (int)s.ld; p.K = 2 * s.N;
         p.A[0] = u.St[0]; p.am = plain(u.ldS);
@@ -336,6 +358,16 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.C[0] = dP; p.Cin[0] = dP; p.cm = plain(s.ld); p.cn = plain(1);
         p.beta = 1.f;
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
+    } else {   // N % 4 != 0: the concatenated K map would leave the float4 fast path -> two accumulating launches
+        for (int b = 0; b < 2; ++b) {
+            GemmP p = gp();
+            p.M = s.N; p.N = (int)s.ld; p.K = s.N;
+            p.A[0] = u.St[b]; p.am = plain(u.ldS); p.ak = plain(1);
+            p.B[0] = dP + (long long)(1 + b * (s.K - 1)) * s.PS; p.bk = plain(s.ld); p.bn = plain(1);
+            p.C[0] = dP; p.Cin[0] = dP; p.cm = plain(s.ld); p.cn = plain(1);
+            p.beta = 1.f;
+            CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
+        }
     }
     return 0;
 }

@@ -139,6 +139,249 @@ __global__ __launch_bounds__(64 * NF) void prop_small_kernel(const PropP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused two-hop variants (cheb_k = 3).  A workgroup owns ALL N rows of its 64 columns, so the second
+// hop needs nothing from other workgroups: the hop-1 result is converted from the accumulators
+// straight into the next B image (each lane owns 4 consecutive rows = one 8-byte half of a B-fragment
+// vector) and S stays in registers for both hops.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+struct PropBlock {
+    static constexpr int KS = 2 * NF;
+    // stage 64 columns of a plane into the B image (see prop_small_kernel)
+    static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, long long ld, int N,
+                                                 int ncols, int colbase, int tid) {
+        const int cg = tid & 15, kg = tid >> 4;
+        const int col = colbase + 4 * cg;
+        const bool cv = col < ncols;
+        float v[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 8 * kg + i;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cv && k < N) t = *reinterpret_cast<const float4*>(X + (long long)k * ld + col);
+            v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+        }
+        const int ct = cg >> 3, ks = kg >> 1, kqq = kg & 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float col8[8] = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
+            uint4 h, l;
+            split8(col8, h, l);
+            const int slot = c * 8 + (cg & 7) + 32 * kqq;
+            img[((ct * KS + ks) * 2 + 0) * 64 + slot] = h;
+            img[((ct * KS + ks) * 2 + 1) * 64 + slot] = l;
+        }
+    }
+    static __device__ __forceinline__ void load_a(const uint4* __restrict__ sfw, uint4 (&ah)[KS], uint4 (&al)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ah[ks] = sfw[(ks * 2 + 0) * 64];
+            al[ks] = sfw[(ks * 2 + 1) * 64];
+        }
+    }
+    // acc[t] += A x img[t]; the two column tiles form two independent accumulator chains
+    static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[KS], const uint4 (&al)[KS],
+                                               f32x16 (&acc)[2], int lane) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+            const bf16x8 b0h = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 0) * 64 + lane]);
+            const bf16x8 b0l = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 1) * 64 + lane]);
+            const bf16x8 b1h = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 0) * 64 + lane]);
+            const bf16x8 b1l = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 1) * 64 + lane]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b1h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1l, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1h, acc[1], 0, 0, 0);
+        }
+    }
+    // values val[t][v] in C/D layout (wave w = rows 32w..32w+31) -> B image of the next hop.
+    // lane (slot, kq) holds rows 8g + 4kq + 0..3 for g = v>>2: the kq-th 8-byte half of the vector
+    // (k-step 2w + (g>>1), k-half g&1, slot).
+    static __device__ __forceinline__ void to_img(uint4* img, const f32x16 (&val)[2], int w, int lane) {
+        const int l31 = lane & 31, kq = lane >> 5;
+        uint2* img2 = reinterpret_cast<uint2*>(img);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float a0 = val[t][4 * g], a1 = val[t][4 * g + 1], a2 = val[t][4 * g + 2], a3 = val[t][4 * g + 3];
+                const unsigned h01 = cvt_pk_bf16(a0, a1), h23 = cvt_pk_bf16(a2, a3);
+                const unsigned l01 = cvt_pk_bf16(a0 - __uint_as_float(h01 << 16), a1 - __uint_as_float(h01 & 0xFFFF0000u));
+                const unsigned l23 = cvt_pk_bf16(a2 - __uint_as_float(h23 << 16), a3 - __uint_as_float(h23 & 0xFFFF0000u));
+                const int ks = 2 * w + (g >> 1);
+                const int slot = l31 + 32 * (g & 1);
+                img2[(((t * KS + ks) * 2 + 0) * 64 + slot) * 2 + kq] = make_uint2(h01, h23);
+                img2[(((t * KS + ks) * 2 + 1) * 64 + slot) * 2 + kq] = make_uint2(l01, l23);
+            }
+    }
+};
+
+struct Prop2P {
+    const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
+    float* base;                // plane set (Z for forward, dP for backward)
+    long long PS, ld;
+    int N, ncols;
+};
+
+// forward, one workgroup per (64 columns, support s = blockIdx.y):
+//   plane[1+2s] = S_s plane[0] ;  plane[2+2s] = 2 S_s plane[1+2s] - plane[0]      (model/MegaCRN.py:20-25)
+template <int NF>
+__global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
+    using PB = PropBlock<NF>;
+    constexpr int KS = 2 * NF;
+    __shared__ uint4 img[2 * KS * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = blockIdx.y, colbase = blockIdx.x * 64;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int cperm = 4 * (l31 & 7) + (l31 >> 3);
+    const float* __restrict__ X0 = p.base;
+    float* __restrict__ X1 = p.base + (long long)(1 + 2 * s) * p.PS;
+    float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
+
+    uint4 ah[KS], al[KS];
+    PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    PB::stage(img, X0, p.ld, p.N, p.ncols, colbase, tid);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    PB::mma(img, ah, al, acc, lane);
+    // X1 out (fp32) + next image
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = colbase + 32 * t + cperm;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N && col < p.ncols) X1[(long long)r * p.ld + col] = acc[t][v];
+        }
+    }
+    __syncthreads();                                   // every wave finished reading the hop-1 image
+    PB::to_img(img, acc, w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    PB::mma(img, ah, al, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = colbase + 32 * t + cperm;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N && col < p.ncols) {
+                const long long off = (long long)r * p.ld + col;
+                X2[off] = 2.f * acc[t][v] - X0[off];
+            }
+        }
+    }
+}
+
+// backward, one workgroup per 64 columns, both supports:
+//   d1t_s = dP[1+2s] + S_s^T dP[2+2s]   (written back to dP[1+2s])
+//   dP[0] += S_1^T d1t_1 + S_2^T d1t_2
+template <int NF>
+__global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
+    using PB = PropBlock<NF>;
+    constexpr int KS = 2 * NF;
+    __shared__ uint4 img[2 * KS * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int colbase = blockIdx.x * 64;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int cperm = 4 * (l31 & 7) + (l31 >> 3);
+    float* __restrict__ D0 = p.base;
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
+        const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
+        int opq = 0;                                   // opaque zero: keeps the 32 element offsets below from
+        asm volatile("" : "+s"(opq));                  // being hoisted out of the support loop (64 VGPRs)
+        const int ldi = (int)p.ld + opq;
+        uint4 ah[KS], al[KS];
+        PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+        if (s > 0) __syncthreads();                    // previous image fully consumed
+        PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        PB::mma(img, ah, al, acc, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __builtin_amdgcn_sched_barrier(0);         // keep the 32 in-flight loads of one tile from piling up
+            const int col = colbase + 32 * t + cperm;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+                if (r < p.N && col < p.ncols) {
+                    const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
+                    const float d = acc[t][v] + D1[off];
+                    acc[t][v] = d;
+                    D1[off] = d;
+                } else {
+                    acc[t][v] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        PB::to_img(img, acc, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        PB::mma(img, ah, al, acc, lane);
+        // dP[0] += S_s^T d1t_s : read-modify-write by the same lane for both supports (fixed order)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int col = colbase + 32 * t + cperm;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+                if (r < p.N && col < p.ncols) {
+                    const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
+                    D0[off] = D0[off] + acc[t][v];
+                }
+            }
+        }
+    }
+}
+
+#define MCRN_NF_SWITCH(KERN, GRID, P)                                                        \
+    switch (NF) {                                                                            \
+        case 1: hipLaunchKernelGGL(KERN<1>, GRID, dim3(64), 0, st, P); break;                \
+        case 2: hipLaunchKernelGGL(KERN<2>, GRID, dim3(128), 0, st, P); break;               \
+        case 3: hipLaunchKernelGGL(KERN<3>, GRID, dim3(192), 0, st, P); break;               \
+        case 4: hipLaunchKernelGGL(KERN<4>, GRID, dim3(256), 0, st, P); break;               \
+        case 5: hipLaunchKernelGGL(KERN<5>, GRID, dim3(320), 0, st, P); break;               \
+        case 6: hipLaunchKernelGGL(KERN<6>, GRID, dim3(384), 0, st, P); break;               \
+        case 7: hipLaunchKernelGGL(KERN<7>, GRID, dim3(448), 0, st, P); break;               \
+        default: hipLaunchKernelGGL(KERN<8>, GRID, dim3(512), 0, st, P); break;              \
+    }
+static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
+    const int NF = (p.N + 31) / 32;
+    dim3 grid((p.ncols + 63) / 64, 2);
+    MCRN_NF_SWITCH(prop2_fwd_kernel, grid, p)
+    return hipGetLastError();
+}
+static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
+    const int NF = (p.N + 31) / 32;
+    dim3 grid((p.ncols + 63) / 64, 1);
+    MCRN_NF_SWITCH(prop2_bwd_kernel, grid, p)
+    return hipGetLastError();
+}
+
 static inline bool prop_small_ok(int N, long long ld, int ncols) {
     return N <= 256 && (ncols % 4) == 0 && (ld % 4) == 0;
 }
