@@ -152,6 +152,16 @@ int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, flo
                         float beta2, float eps, int step, float max_norm, float grad_scale,
                         float* scratch, float* total_norm_out, void* stream);
 
+/* ---- trainer loss, forward + backward (model/traintest_MegaCRN.py:118-125, model/utils.py:126-133) ----
+ * loss = masked_mae(output*std+mean, labels*std+mean) + lamb*TripletMarginLoss(margin)(query,pos,neg)
+ *        + lamb1*MSELoss(query,pos), pos/neg treated as constants (the trainer detaches them).
+ * losses (device, 4 floats) = {total, masked_mae, triplet, mse}; d_output, d_query = gradients of `total`.
+ * scratch: >= 4104 floats. */
+int mcrn_loss_fwd_bwd(int B, int T, int N, int output_dim, int D, const float* output, const float* labels,
+                      const float* query, const float* pos, const float* neg, float mean, float std, float lamb,
+                      float lamb1, float margin, float* scratch, float* losses, float* d_output, float* d_query,
+                      void* stream);
+
 /* ---- test hook: C = alpha*op(A)*op(B) + beta*C on the library's MFMA GEMM ---- */
 /* A is (M,K) row-major if !transA else (K,M); B is (K,N) if !transB else (N,K); C (M,N). */
 int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B,

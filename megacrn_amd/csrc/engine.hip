@@ -1251,6 +1251,27 @@ int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, flo
     return 0;
 }
 
+// ---- fused trainer loss ---------------------------------------------------------------------------
+int mcrn_loss_fwd_bwd(int B, int T, int N, int od, int D, const float* output, const float* labels,
+                      const float* query, const float* pos, const float* neg, float mean, float stdv, float lamb,
+                      float lamb1, float margin, float* scratch, float* losses, float* d_output, float* d_query,
+                      void* stream) {
+    if (B < 1 || T < 1 || N < 1 || od < 1 || D < 1 || !output || !labels || !query || !pos || !neg || !scratch ||
+        !losses || !d_output || !d_query)
+        FAIL("loss: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nout = (long long)B * T * N * od, rows = (long long)B * N;
+    int nblk = cdiv(nout, 256 * 4);
+    if (nblk > 1024) nblk = 1024;
+    LAUNCH(k_loss_stage1, dim3(nblk), dim3(256), 0, st, output, labels, nout, query, pos, neg, rows, D, mean, stdv,
+           lamb, lamb1, margin, scratch, d_query);
+    LAUNCH(k_loss_stage2, dim3(1), dim3(64), 0, st, (const float*)scratch, nblk, nout, rows, D, lamb, lamb1, losses,
+           scratch + 4096);
+    LAUNCH(k_loss_dout, dim3(cdiv(nout, 256)), dim3(256), 0, st, output, labels, nout, mean, stdv,
+           (const float*)(scratch + 4096), d_output);
+    return 0;
+}
+
 // ---- GEMM test hook -----------------------------------------------------------------------------
 int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B, float* C, float alpha,
                   float beta, int nsplit, float* slabs, void* stream) {

@@ -485,6 +485,83 @@ __global__ void k_copy2d(float* __restrict__ dst, long long ldd, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// trainer loss, forward + backward fused (model/traintest_MegaCRN.py:118-125, model/utils.py:126-133):
+//   loss = masked_mae(inv(output), inv(labels)) + lamb * TripletMarginLoss(q, pos, neg) + lamb1 * MSE(q, pos)
+// stage1: deterministic per-block partial sums {mask count, sum |diff|*mask, sum triplet, sum sq} and d_query
+// stage2: one wave reduces the partials -> losses[0..3], scalars[0] = 1/mask count
+// stage3: d_output = sign(diff) * mask * std / mask count
+// inverse_transform is evaluated as two roundings (mul, then add) like the reference's two torch ops:
+// a fused multiply-add would not map the standardised missing value back to exactly 0 and break the mask.
+// ---------------------------------------------------------------------------------------------
+// x*std + mean with TWO roundings (the asm barrier keeps hipcc from contracting it into one FMA)
+__device__ __forceinline__ float inv_transform(float x, float stdv, float mean) {
+    float t = x * stdv;
+    asm volatile("" : "+v"(t));
+    return t + mean;
+}
+__global__ void k_loss_stage1(const float* __restrict__ out, const float* __restrict__ lab, long long nout,
+                              const float* __restrict__ q, const float* __restrict__ pos,
+                              const float* __restrict__ neg, long long rows, int D, float mean, float stdv,
+                              float lamb, float lamb1, float margin, float* __restrict__ part,
+                              float* __restrict__ dq) {
+    __shared__ float sh[4][4];
+    float cnt = 0.f, sab = 0.f, trip = 0.f, sq = 0.f;
+    const long long gs = (long long)gridDim.x * blockDim.x, g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = g0; i < nout; i += gs) {
+        const float yt = inv_transform(lab[i], stdv, mean);
+        const float yp = inv_transform(out[i], stdv, mean);
+        if (yt != 0.f) { cnt += 1.f; sab += fabsf(yp - yt); }
+    }
+    const float inv_rows = 1.f / (float)rows, inv_rd = 1.f / ((float)rows * (float)D);
+    for (long long r = g0; r < rows; r += gs) {
+        const float* qr = q + r * D; const float* pr = pos + r * D; const float* nr = neg + r * D;
+        float lp = 0.f, ln = 0.f, s2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float a = qr[d], dp = a - pr[d] + 1e-6f, dn = a - nr[d] + 1e-6f, e = a - pr[d];
+            lp += dp * dp; ln += dn * dn; s2 += e * e;
+        }
+        lp = sqrtf(lp); ln = sqrtf(ln);
+        const float v = lp - ln + margin;
+        const bool act = v > 0.f;
+        if (act) trip += v;
+        sq += s2;
+        const float cp = act ? lamb * inv_rows / lp : 0.f, cn = act ? lamb * inv_rows / ln : 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float a = qr[d];
+            dq[r * D + d] = cp * (a - pr[d] + 1e-6f) - cn * (a - nr[d] + 1e-6f) + lamb1 * 2.f * inv_rd * (a - pr[d]);
+        }
+    }
+    cnt = wave_sum(cnt); sab = wave_sum(sab); trip = wave_sum(trip); sq = wave_sum(sq);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w][0] = cnt; sh[w][1] = sab; sh[w][2] = trip; sh[w][3] = sq; }
+    __syncthreads();
+    if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ void k_loss_stage2(const float* __restrict__ part, int nblk, long long nout, long long rows, int D,
+                              float lamb, float lamb1, float* __restrict__ losses, float* __restrict__ scal) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 64)
+        for (int j = 0; j < 4; ++j) a[j] += part[b * 4 + j];
+    for (int j = 0; j < 4; ++j) a[j] = wave_sum(a[j]);
+    if (threadIdx.x == 0) {
+        const float l1 = a[0] > 0.f ? a[1] / a[0] : 0.f;        // mean(|d| * mask / mean(mask)); NaN -> 0 (:131)
+        const float l2 = a[2] / (float)rows, l3 = a[3] / ((float)rows * (float)D);
+        losses[0] = l1 + lamb * l2 + lamb1 * l3; losses[1] = l1; losses[2] = l2; losses[3] = l3;
+        scal[0] = a[0] > 0.f ? 1.f / a[0] : 0.f;
+    }
+}
+__global__ void k_loss_dout(const float* __restrict__ out, const float* __restrict__ lab, long long nout,
+                            float mean, float stdv, const float* __restrict__ scal, float* __restrict__ dout) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout) return;
+    const float yt = inv_transform(lab[i], stdv, mean);
+    const float yp = inv_transform(out[i], stdv, mean);
+    const float d = yp - yt;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dout[i] = yt != 0.f ? sg * stdv * scal[0] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // flat clip_grad_norm_ + Adam   (model/traintest_MegaCRN.py:104,129-130)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_sumsq_stage1(const float* __restrict__ g, long long n, float scale, float* __restrict__ part) {

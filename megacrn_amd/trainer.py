@@ -27,7 +27,7 @@ def masked_mae_loss(y_pred, y_true):
 
 class FlatTrainer:
     def __init__(self, model, *, lr=0.01, eps=1e-3, betas=(0.9, 0.999), max_grad_norm=5.0, lamb=0.01,
-                 lamb1=0.01, scaler_mean=0.0, scaler_std=1.0, process_group=None, autotune=True):
+                 lamb1=0.01, scaler_mean=0.0, scaler_std=1.0, process_group=None, autotune=True, fused_loss=True):
         if model.num_layers != 1:
             raise ValueError("FlatTrainer drives the fused num_layers==1 path")
         self.model = model
@@ -36,6 +36,7 @@ class FlatTrainer:
         self.mean, self.std = float(scaler_mean), float(scaler_std)
         self.group = process_group
         self.autotune = autotune
+        self.fused_loss = fused_loss
         self.world = dp.world_size(process_group)
         params = list(model._fused_params())
         dev = params[0].device
@@ -54,6 +55,8 @@ class FlatTrainer:
         self.v = torch.zeros(o, device=dev)
         self.scratch = torch.zeros(2048, device=dev)
         self.total_norm = torch.zeros(1, device=dev)
+        self.loss_scratch = torch.zeros(4104, device=dev)
+        self.losses = torch.zeros(4, device=dev)
         self._gviews = []
         for p, off, n in zip(params, offs, sizes):
             self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
@@ -87,6 +90,8 @@ class FlatTrainer:
             B, N, To, od, D = self.d.B, self.d.N, self.d.T_out, self.d.output_dim, self.d.mem_dim
             self.out = torch.empty(B, To, N, od, device=dev)
             self.hatt, self.q, self.pos, self.neg = (torch.empty(B, N, D, device=dev) for _ in range(4))
+            self.d_out = torch.empty_like(self.out)
+            self.d_q = torch.empty_like(self.q)
             self._dims_key = key
 
     def loss_fn(self, output, query, pos, neg, labels):
@@ -111,10 +116,19 @@ class FlatTrainer:
                                      tarr, self._ws.data_ptr(), nb, self.out.data_ptr(), self.hatt.data_ptr(),
                                      self.q.data_ptr(), self.pos.data_ptr(), self.neg.data_ptr(), st),
               "mcrn_model_forward")
-        out_l = self.out.detach().requires_grad_()
-        q_l = self.q.detach().requires_grad_()
-        loss = self.loss_fn(out_l, q_l, self.pos, self.neg, labels)
-        d_out, d_q = torch.autograd.grad(loss, [out_l, q_l])
+        if self.fused_loss:     # 3 HIP launches instead of ~25 torch kernels + an autograd pass
+            d = self.d
+            check(lib.mcrn_loss_fwd_bwd(d.B, d.T_out, d.N, d.output_dim, d.mem_dim, self.out.data_ptr(),
+                                        labels.data_ptr(), self.q.data_ptr(), self.pos.data_ptr(),
+                                        self.neg.data_ptr(), self.mean, self.std, self.lamb, self.lamb1, 1.0,
+                                        self.loss_scratch.data_ptr(), self.losses.data_ptr(),
+                                        self.d_out.data_ptr(), self.d_q.data_ptr(), st), "mcrn_loss_fwd_bwd")
+            d_out, d_q, loss = self.d_out, self.d_q, self.losses[0]
+        else:
+            out_l = self.out.detach().requires_grad_()
+            q_l = self.q.detach().requires_grad_()
+            loss = self.loss_fn(out_l, q_l, self.pos, self.neg, labels)
+            d_out, d_q = torch.autograd.grad(loss, [out_l, q_l])
         check(lib.mcrn_model_backward(C.byref(self.d), C.byref(ps), tarr, d_out.data_ptr(), None, d_q.data_ptr(),
                                       None, None, self._ws.data_ptr(), nb, C.byref(gs), st), "mcrn_model_backward")
         if self.world > 1:
@@ -125,4 +139,4 @@ class FlatTrainer:
                                       self.step_count, self.max_grad_norm, 1.0 / self.world,
                                       self.scratch.data_ptr(), self.total_norm.data_ptr(), st), "mcrn_flat_clip_adam")
         self.batches_seen += 1
-        return loss.detach()
+        return loss.detach().clone() if self.fused_loss else loss.detach()

@@ -260,6 +260,26 @@ def test_flat_clip_adam(amd):
         assert relerr(tp.cpu().numpy(), P["w"]) < 1e-5
 
 
+def test_fused_loss_matches_oracle(amd):
+    from megacrn_amd._lib import lib, check
+    rng = np.random.default_rng(3)
+    B, T, N, D = 5, 7, 23, 12
+    out, q, pos, neg = (rng.standard_normal(s).astype(np.float32) for s in ((B, T, N, 1), (B, N, D), (B, N, D), (B, N, D)))
+    lab = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    lab[rng.random(lab.shape) < 0.2] = np.float32((0.0 - SC_MEAN) / SC_STD)      # masked entries
+    (l, l1, l2, l3), d_out, d_q = O.loss_fwd_bwd((out, None, q, pos, neg), lab, SC_MEAN, SC_STD)
+    t = [dev(a) for a in (out, lab, q, pos, neg)]
+    scratch, losses = torch.zeros(4104, device="cuda"), torch.zeros(4, device="cuda")
+    g_out, g_q = torch.empty_like(t[0]), torch.empty_like(t[2])
+    check(lib.mcrn_loss_fwd_bwd(B, T, N, 1, D, *[a.data_ptr() for a in t], SC_MEAN, SC_STD, 0.01, 0.01, 1.0,
+                                scratch.data_ptr(), losses.data_ptr(), g_out.data_ptr(), g_q.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream), "loss")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), [l, l1, l2, l3], rtol=2e-5)
+    assert (g_out.cpu().numpy() != 0).sum() == (d_out != 0).sum()               # identical mask
+    assert relerr(g_out.cpu().numpy(), d_out) < 1e-5 and relerr(g_q.cpu().numpy(), d_q) < 1e-5
+
+
 def test_trainer_matches_oracle_trajectory(amd):
     """FlatTrainer (forward, loss, backward into the flat bucket, fused clip+Adam) against the
     reference's own 3-step loss trajectory (tests/golden, `odd` case)."""
