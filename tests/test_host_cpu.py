@@ -71,3 +71,35 @@ def test_cpu_tensors_fail_loudly():
     model = megacrn_amd.MegaCRN(5, 1, 1, 2, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.randn(1, 2, 5, 1), torch.randn(1, 2, 5, 1))
+
+
+def test_loader_shuffles_once_and_pads_with_last_sample():
+    """model/utils.py:6-43 semantics of the counterpart DataLoader."""
+    from megacrn_amd.train import DataLoader, StandardScaler
+    xs = np.arange(10, dtype=np.float64).reshape(10, 1)
+    ys = xs * 10
+    dl = DataLoader(xs, ys, batch_size=4, shuffle=False)
+    batches = list(dl.get_iterator())
+    assert dl.size == 12 and dl.num_batch == 3
+    assert batches[-1][0].ravel().tolist() == [8, 9, 9, 9]          # padded by repeating the last sample
+    np.random.seed(0)
+    dl = DataLoader(xs, ys, batch_size=4, shuffle=True)
+    e1 = np.concatenate([b[0] for b in dl.get_iterator()]).ravel()
+    e2 = np.concatenate([b[0] for b in dl.get_iterator()]).ravel()
+    assert (e1 == e2).all() and sorted(e1.tolist()) == sorted([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9])  # one permutation, reused
+    assert (np.concatenate([b[1] for b in dl.get_iterator()]).ravel() == e1 * 10).all()
+    sc = StandardScaler(mean=54.4, std=19.5)
+    z = sc.transform(np.array([0.0, 54.4, 73.9]))
+    np.testing.assert_allclose(sc.inverse_transform(z), [0.0, 54.4, 73.9], atol=1e-12)
+
+
+def test_train_cli_defaults_match_reference_flags():
+    from megacrn_amd.train import build_parser, synthetic_windows
+    a = build_parser().parse_args([])
+    assert (a.num_nodes, a.seq_len, a.horizon, a.rnn_units, a.mem_num, a.mem_dim) == (207, 12, 12, 64, 20, 64)
+    assert (a.max_diffusion_step, a.batch_size, a.lr, a.epsilon, a.max_grad_norm) == (3, 64, 0.01, 1e-3, 5)
+    assert a.steps == [50, 100] and a.lr_decay_ratio == 0.1 and a.patience == 20 and a.epochs == 200
+    assert a.lamb == 0.01 and a.lamb1 == 0.01 and a.cl_decay_steps == 2000 and a.use_curriculum_learning is True
+    x, y = synthetic_windows(5, 12, 7, 0)
+    assert x.shape == (5, 12, 7, 2) and y.shape == (5, 12, 7, 2)
+    assert (x[..., 0] == 0).mean() > 0.02 and 0 <= x[..., 1].min() and x[..., 1].max() < 1
