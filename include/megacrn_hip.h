@@ -80,6 +80,9 @@ int mcrn_version(void);
  * mcrn_dims_t.precision).  Returns 0 or MCRN_EINVAL. */
 int mcrn_set_precision(int precision);
 int mcrn_get_precision(void);
+/* adjacency-gradient GEMMs run on an internal low-priority helper stream, forked from and joined back
+ * to `stream` with events inside each call (default on); 0 keeps every kernel on `stream`. */
+int mcrn_set_side_stream(int enable);
 
 /* ---- whole model: MegaCRN.forward, model/MegaCRN.py:168-194, and its autograd backward ---- */
 size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d);

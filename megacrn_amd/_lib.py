@@ -18,7 +18,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision",
+    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
 ]
 
 
@@ -103,6 +103,8 @@ def _load():
     lib.mcrn_set_precision.restype = i
     lib.mcrn_set_precision.argtypes = [i]
     lib.mcrn_get_precision.restype = i
+    lib.mcrn_set_side_stream.restype = i
+    lib.mcrn_set_side_stream.argtypes = [i]
     lib.mcrn_model_autotune.restype = i
     lib.mcrn_model_autotune.argtypes = [C.POINTER(Dims), vp, sz, vp]
     lib.mcrn_autotune_entries.restype = i

@@ -159,6 +159,46 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
     MCRN_PROF_WRAP(role, launch_prop_small(p, nbatch, st), ex, alg > 0 ? alg : ex);
     return 0;
 }
+// ---- helper stream for work that is off the critical path (adjacency-gradient GEMMs) -------------
+// Fork/join with events inside one entry-point call: the caller's stream stays the only stream the
+// caller has to reason about (every side launch is joined back before the call returns its last kernel).
+struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t ready[2], done[2], join;
+    bool ok = false, pending[2] = {false, false}, any = false;
+};
+static Side g_side;
+static bool g_use_side = true;
+static int side_init() {
+    if (g_side.ok) return 0;
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CK(hipStreamCreateWithPriority(&g_side.st, hipStreamNonBlocking, lo));     // lowest priority: fills idle CUs
+    for (int i = 0; i < 2; ++i) {
+        CK(hipEventCreateWithFlags(&g_side.ready[i], hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming));
+    }
+    CK(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+    g_side.ok = true;
+    return 0;
+}
+// main stream must not overwrite scratch plane set `buf` while a side GEMM still reads it
+static int side_guard(int buf, hipStream_t st) {
+    if (g_side.ok && g_side.pending[buf]) {
+        CK(hipStreamWaitEvent(st, g_side.done[buf], 0));
+        g_side.pending[buf] = false;
+    }
+    return 0;
+}
+static int side_join(hipStream_t st) {
+    if (g_side.ok && g_side.any) {
+        CK(hipEventRecord(g_side.join, g_side.st));
+        CK(hipStreamWaitEvent(st, g_side.join, 0));
+        g_side.any = false; g_side.pending[0] = g_side.pending[1] = false;
+    }
+    return 0;
+}
+
 // ---- bump allocator over the caller's workspace -------------------------------------------
 struct Bump {
     char* base;
@@ -279,7 +319,9 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
-                         const float* X, float* dP, hipStream_t st) {
+                         const float* X, float* dP, hipStream_t st, int buf = 0) {
+    const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
+    if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
     {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
         GemmP p = gp();
         p.M = (int)s.R; p.N = s.G * s.Cp; p.K = O;
@@ -336,7 +378,15 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             p.C[b] = u.dS + (long long)b * u.nslab * u.slab;
             p.Cin[b] = p.C[b];
         }
-        CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
+        if (side) {   // off the critical path: only sup_bwd_core (after all BPTT) consumes the slabs
+            CK(hipEventRecord(g_side.ready[buf], st));
+            CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
+            CKI(gemm(p, true, true, u.nslab, ROLE_DS, g_side.st));
+            CK(hipEventRecord(g_side.done[buf], g_side.st));
+            g_side.pending[buf] = true; g_side.any = true;
+        } else {
+            CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
+        }
     }
     if (fused_bwd) {
         // done above
@@ -418,9 +468,9 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st) {
     const long long RH = s.R * s.H;
     LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st));
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st));
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1));
     LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dP, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     return 0;
 }
@@ -826,7 +876,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st));
     CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
     CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
-    // ---- adjacency backward (all dS contributions are in the slabs now)
+    // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
+    CKI(side_join(st));
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS,
                      P.dS + (long long)P.nslabS * u.slab, P.ldS, P.nslabS, u.slab, g->We1, g->We2, P.dMem_s, st));
     LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_W,
@@ -990,6 +1041,7 @@ int mcrn_set_precision(int precision) {
     return 0;
 }
 int mcrn_get_precision(void) { return g_precision; }
+int mcrn_set_side_stream(int enable) { g_use_side = enable != 0; return 0; }
 
 int mcrn_prof_begin(int role) {
     if (role < 0 || role >= ROLE_COUNT) FAIL("prof: bad role %d", role);
@@ -1121,6 +1173,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     CK(hipMemsetAsync(P.dWs, 0, (size_t)s.G * s.Cp * O * NSLAB_W * sizeof(float), st));
     CKI(bnc_to_rows(P.dY, O, 0, O, dy, B, N, st));
     CKI(agcn_bwd_core(s, u, P.dY, O, P.Wd, P.Z, P.dP, st));
+    CKI(side_join(st));
     CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dY, O, P.dWs, st));
     CKI(wunprep(dW, P.dWs, s, O, st));
     CKI(colsum(P.dY, O, s.R, O, P.part, db, 0, st));
@@ -1180,6 +1233,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CKI(bnc_to_rows(P.dacc, H, 0, H, dhn, B, N, st));
     CellW w{P.Wf[0], P.Wd[0], nullptr, P.Wf[1], P.Wd[1], nullptr};
     CKI(cell_bwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.dacc, P.dU, P.dG, P.dP, P.dQ, P.dacc, P.dxin, st));
+    CKI(side_join(st));
     CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dG, 2 * H, P.dWs[0], st));
     CKI(agcn_wgrad(s, P.Y, s.ZT, 1, P.dU, H, P.dWs[1], st));
     CKI(wunprep(dgate_w, P.dWs[0], s, 2 * H, st));

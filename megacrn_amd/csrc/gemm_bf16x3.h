@@ -58,7 +58,7 @@ struct TileX {
     int rem[NP][NU];
     long long roff[NP];
     int row[NP], kg[NP];
-    float v[NP][8];
+    struct Regs { float v[NP][8]; };     // one pipeline stage of raw fp32 operand data
 
     __device__ __forceinline__ void init(const float* __restrict__ base, int tid, int row0, int nrows,
                                          const Dim2& d, int kbeg, int kinner, long long khi, long long klo) {
@@ -98,7 +98,8 @@ struct TileX {
             }
     }
     // full tile, fast path: the pointers already address this tile
-    __device__ __forceinline__ void load_fast(long long klo) {
+    __device__ __forceinline__ void load_fast(Regs& R, long long klo) {
+        float (&v)[NP][8] = R.v;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (KC) {
@@ -114,8 +115,9 @@ struct TileX {
         }
     }
     // any tile, general path (one division per group + bounds); independent of the incremental pointers
-    __device__ __forceinline__ void load_slow(const float* __restrict__ base, int k0, int kend, int kinner,
+    __device__ __forceinline__ void load_slow(Regs& R, const float* __restrict__ base, int k0, int kend, int kinner,
                                               long long khi, long long klo) {
+        float (&v)[NP][8] = R.v;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int k = k0 + 8 * kg[q];
@@ -135,12 +137,12 @@ struct TileX {
             }
         }
     }
-    __device__ __forceinline__ void store(uint4* sHi, uint4* sLo, int tid) const {
+    __device__ __forceinline__ void store(const Regs& R, uint4* sHi, uint4* sLo, int tid) const {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (tid + 256 * q < E * 4) {
                 uint4 h, l;
-                split8(v[q], h, l);
+                split8(R.v[q], h, l);
                 sHi[row[q] * 5 + kg[q]] = h;
                 sLo[row[q] * 5 + kg[q]] = l;
             }
@@ -155,11 +157,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     constexpr int FM = WM / 32, FN = WN / 32;
     using TA = TileX<BM, AKC>;
     using TB = TileX<BN, BKC>;
-    __shared__ uint4 smem[2 * TA::SZ + 2 * TB::SZ];
-    uint4* sAh = smem;
-    uint4* sAl = smem + TA::SZ;
-    uint4* sBh = smem + 2 * TA::SZ;
-    uint4* sBl = smem + 2 * TA::SZ + TB::SZ;
+    constexpr int STAGE = 2 * TA::SZ + 2 * TB::SZ;         // uint4 per LDS stage (A hi, A lo, B hi, B lo)
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // 2 stages
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -191,59 +190,77 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    // tiles [kbeg, kfull) are complete (32 valid k); the last one may be a partial tail
-    const int kfull = kbeg + ((kend - kbeg) & ~31);
-#define MCRN_LOAD_TILE(K0)                                                                   \
-    do {                                                                                     \
-        const bool full_ = (K0) < kfull;                                                     \
-        if (afast && full_) ta.load_fast(p.ak.lo); else ta.load_slow(Ab, (K0), kend, p.ak.inner, akhi, p.ak.lo); \
-        if (bfast && full_) tb.load_fast(p.bk.lo); else tb.load_slow(Bb, (K0), kend, p.bk.inner, bkhi, p.bk.lo); \
+    // Software pipeline: tile t is computed from LDS stage t&1 while tile t+1 sits in registers (converted
+    // and stored to the other LDS stage at the end of the iteration) and tile t+2 is in flight from
+    // L2/HBM - every global load has two iterations to land.  One barrier per K-tile.
+    const int kfull = kbeg + ((kend - kbeg) & ~31);        // tiles below kfull have 32 valid k
+    const int nt = (kend - kbeg + 31) >> 5;
+    int kload = kbeg;                                       // first k of the next tile to request
+#define MCRN_LOAD_TILE(RA, RB)                                                                      \
+    do {                                                                                            \
+        const bool full_ = kload < kfull;                                                           \
+        if (afast && full_) ta.load_fast(RA, p.ak.lo); else ta.load_slow(RA, Ab, kload, kend, p.ak.inner, akhi, p.ak.lo); \
+        if (bfast && full_) tb.load_fast(RB, p.bk.lo); else tb.load_slow(RB, Bb, kload, kend, p.bk.inner, bkhi, p.bk.lo); \
+        kload += 32;                                                                                \
+        if (afast) ta.advance(p.ak.inner, akhi, p.ak.lo);                                           \
+        if (bfast) tb.advance(p.bk.inner, bkhi, p.bk.lo);                                           \
     } while (0)
-    MCRN_LOAD_TILE(kbeg);
-    ta.store(sAh, sAl, tid);
-    tb.store(sBh, sBl, tid);
-    __syncthreads();
-
+#define MCRN_STORE_TILE(RA, RB, STG)                                                                \
+    do {                                                                                            \
+        uint4* b_ = smem + (STG) * STAGE;                                                           \
+        ta.store(RA, b_, b_ + TA::SZ, tid);                                                         \
+        tb.store(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                               \
+    } while (0)
     const int l31 = lane & 31, kq = lane >> 5;
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        const bool more = k0 + 32 < kend;
-        if (more) {
-            if (afast) ta.advance(p.ak.inner, akhi, p.ak.lo);
-            if (bfast) tb.advance(p.bk.inner, bkhi, p.bk.lo);
-            MCRN_LOAD_TILE(k0 + 32);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int o = (wm * WM + i * 32 + l31) * 5 + ks * 2 + kq;
-                ah[i] = __builtin_bit_cast(bf16x8, sAh[o]);
-                al[i] = __builtin_bit_cast(bf16x8, sAl[o]);
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int o = (wn * WN + j * 32 + l31) * 5 + ks * 2 + kq;
-                bh[j] = __builtin_bit_cast(bf16x8, sBh[o]);
-                bl[j] = __builtin_bit_cast(bf16x8, sBl[o]);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
+#define MCRN_COMPUTE(STG)                                                                           \
+    do {                                                                                            \
+        const uint4* sAh = smem + (STG) * STAGE;                                                    \
+        const uint4* sAl = sAh + TA::SZ;                                                            \
+        const uint4* sBh = sAh + 2 * TA::SZ;                                                        \
+        const uint4* sBl = sBh + TB::SZ;                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                         \
+            bf16x8 ah[FM], al[FM], bh[FN], bl[FN];                                                  \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                       \
+                const int o = (wm * WM + i * 32 + l31) * 5 + ks * 2 + kq;                           \
+                ah[i] = __builtin_bit_cast(bf16x8, sAh[o]);                                         \
+                al[i] = __builtin_bit_cast(bf16x8, sAl[o]);                                         \
+            }                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                       \
+                const int o = (wn * WN + j * 32 + l31) * 5 + ks * 2 + kq;                           \
+                bh[j] = __builtin_bit_cast(bf16x8, sBh[o]);                                         \
+                bl[j] = __builtin_bit_cast(bf16x8, sBl[o]);                                         \
+            }                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                }                                                                                   \
+        }                                                                                           \
+    } while (0)
+
+    typename TA::Regs ra0, ra1;
+    typename TB::Regs rb0, rb1;
+    MCRN_LOAD_TILE(ra0, rb0);                                // tile 0
+    if (nt > 1) MCRN_LOAD_TILE(ra1, rb1);                    // tile 1
+    MCRN_STORE_TILE(ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        // even tile t: registers set 0 is free (tile t is in LDS stage 0) -> request tile t+2 into it
+        if (t + 2 < nt) MCRN_LOAD_TILE(ra0, rb0);
+        MCRN_COMPUTE(0);
+        if (t + 1 < nt) MCRN_STORE_TILE(ra1, rb1, 1);        // tile t+1 -> stage 1
         __syncthreads();
-        if (more) {
-            ta.store(sAh, sAl, tid);
-            tb.store(sBh, sBl, tid);
-            __syncthreads();
-        }
+        if (t + 1 >= nt) break;
+        // odd tile t+1
+        if (t + 3 < nt) MCRN_LOAD_TILE(ra1, rb1);
+        MCRN_COMPUTE(1);
+        if (t + 2 < nt) MCRN_STORE_TILE(ra0, rb0, 0);        // tile t+2 -> stage 0
+        __syncthreads();
     }
 #undef MCRN_LOAD_TILE
+#undef MCRN_STORE_TILE
+#undef MCRN_COMPUTE
     gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kq, n_blk + wn * WN + l31);
 }
 
@@ -251,7 +268,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one_x3(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
+    constexpr size_t lds = 2 * (2 * TileX<BM, AKC>::SZ + 2 * TileX<BN, BKC>::SZ) * sizeof(uint4);   // 2 stages
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
 template <bool AKC, bool BKC, int ROLE>

@@ -145,13 +145,15 @@ __global__ __launch_bounds__(64 * NF) void prop_small_kernel(const PropP p) {
 // straight into the next B image (each lane owns 4 consecutive rows = one 8-byte half of a B-fragment
 // vector) and S stays in registers for both hops.
 // ---------------------------------------------------------------------------------------------
-template <int NF>
+template <int NF, int CT>      // CT = 32-column tiles per workgroup (1 or 2)
 struct PropBlock {
     static constexpr int KS = 2 * NF;
-    // stage 64 columns of a plane into the B image (see prop_small_kernel)
+    static constexpr int IMG = CT * KS * 2 * 64;     // uint4
+    // stage 32*CT columns of a plane into the B image: thread = (4-column group, 8-k group)
     static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, long long ld, int N,
                                                  int ncols, int colbase, int tid) {
-        const int cg = tid & 15, kg = tid >> 4;
+        const int cg = tid % (8 * CT), kg = tid / (8 * CT);
+        if (kg >= 4 * NF) return;                     // CT == 1: half of the threads have no item
         const int col = colbase + 4 * cg;
         const bool cv = col < ncols;
         float v[8][4];
@@ -180,33 +182,56 @@ struct PropBlock {
             al[ks] = sfw[(ks * 2 + 1) * 64];
         }
     }
-    // acc[t] += A x img[t]; the two column tiles form two independent accumulator chains
+    // acc[t] = A x img[t].  Independent accumulator chains hide the MFMA dependent-issue latency:
+    // CT == 2: the two column tiles; CT == 1: the three split products, summed at the end.
     static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[KS], const uint4 (&al)[KS],
-                                               f32x16 (&acc)[2], int lane) {
+                                               f32x16 (&acc)[CT], int lane) {
+        if constexpr (CT == 2) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
-            const bf16x8 b0h = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 0) * 64 + lane]);
-            const bf16x8 b0l = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 1) * 64 + lane]);
-            const bf16x8 b1h = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 0) * 64 + lane]);
-            const bf16x8 b1l = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 1) * 64 + lane]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b0h, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b1h, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0l, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1l, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0h, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1h, acc[1], 0, 0, 0);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+                const bf16x8 b0h = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 0) * 64 + lane]);
+                const bf16x8 b0l = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 1) * 64 + lane]);
+                const bf16x8 b1h = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 0) * 64 + lane]);
+                const bf16x8 b1l = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 1) * 64 + lane]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b1h, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0l, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1l, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1h, acc[1], 0, 0, 0);
+            }
+        } else {
+            f32x16 a0, a1, a2;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { a0[v] = 0.f; a1[v] = 0.f; a2[v] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, img[(ks * 2 + 0) * 64 + lane]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, img[(ks * 2 + 1) * 64 + lane]);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, a2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[0][v] = (a0[v] + a1[v]) + a2[v];
         }
     }
     // values val[t][v] in C/D layout (wave w = rows 32w..32w+31) -> B image of the next hop.
     // lane (slot, kq) holds rows 8g + 4kq + 0..3 for g = v>>2: the kq-th 8-byte half of the vector
     // (k-step 2w + (g>>1), k-half g&1, slot).
-    static __device__ __forceinline__ void to_img(uint4* img, const f32x16 (&val)[2], int w, int lane) {
+    static __device__ __forceinline__ void to_img(uint4* img, const f32x16 (&val)[CT], int w, int lane) {
         const int l31 = lane & 31, kq = lane >> 5;
         uint2* img2 = reinterpret_cast<uint2*>(img);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float a0 = val[t][4 * g], a1 = val[t][4 * g + 1], a2 = val[t][4 * g + 2], a3 = val[t][4 * g + 3];
@@ -228,73 +253,78 @@ struct Prop2P {
     int N, ncols;
 };
 
-// forward, one workgroup per (64 columns, support s = blockIdx.y):
+// forward, one workgroup per (32*CT columns, support s = blockIdx.y):
 //   plane[1+2s] = S_s plane[0] ;  plane[2+2s] = 2 S_s plane[1+2s] - plane[0]      (model/MegaCRN.py:20-25)
-template <int NF>
+template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
-    using PB = PropBlock<NF>;
+    using PB = PropBlock<NF, CT>;
     constexpr int KS = 2 * NF;
-    __shared__ uint4 img[2 * KS * 2 * 64];
+    __shared__ uint4 img[PB::IMG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = blockIdx.y, colbase = blockIdx.x * 64;
+    const int s = blockIdx.y, colbase = blockIdx.x * 32 * CT;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
     const float* __restrict__ X0 = p.base;
     float* __restrict__ X1 = p.base + (long long)(1 + 2 * s) * p.PS;
     float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
+    const int ldi = (int)p.ld;
 
     uint4 ah[KS], al[KS];
     PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
-    PB::stage(img, X0, p.ld, p.N, p.ncols, colbase, tid);
-    __syncthreads();
-    f32x16 acc[2];
+    // x0 in accumulator layout for the final "2 S x1 - x0": requested now, consumed after both hops, so the
+    // kernel exposes ONE memory round-trip instead of two (the lines are the ones being staged anyway)
+    f32x16 x0c[CT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    PB::mma(img, ah, al, acc, lane);
-    // X1 out (fp32) + next image
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < CT; ++t) {
         const int col = colbase + 32 * t + cperm;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N && col < p.ncols) X1[(long long)r * p.ld + col] = acc[t][v];
+            x0c[t][v] = (r < p.N && col < p.ncols) ? X0[r * ldi + col] : 0.f;
+        }
+    }
+    PB::stage(img, X0, p.ld, p.N, p.ncols, colbase, tid);
+    __syncthreads();
+    f32x16 acc[CT];
+    PB::mma(img, ah, al, acc, lane);
+    // X1 out (fp32) + next image
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = colbase + 32 * t + cperm;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N && col < p.ncols) X1[r * ldi + col] = acc[t][v];
         }
     }
     __syncthreads();                                   // every wave finished reading the hop-1 image
     PB::to_img(img, acc, w, lane);
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     PB::mma(img, ah, al, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < CT; ++t) {
         const int col = colbase + 32 * t + cperm;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
             if (r < p.N && col < p.ncols) {
-                const long long off = (long long)r * p.ld + col;
-                X2[off] = 2.f * acc[t][v] - X0[off];
+                const int off = r * ldi + col;
+                X2[off] = 2.f * acc[t][v] - x0c[t][v];
             }
         }
     }
 }
 
-// backward, one workgroup per 64 columns, both supports:
+// backward, one workgroup per 32*CT columns, both supports:
 //   d1t_s = dP[1+2s] + S_s^T dP[2+2s]   (written back to dP[1+2s])
-//   dP[0] += S_1^T d1t_1 + S_2^T d1t_2
-template <int NF>
+//   dP[0] += S_1^T d1t_1 + S_2^T d1t_2   (read-modify-write by the same lane for both supports: fixed order)
+template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
-    using PB = PropBlock<NF>;
+    using PB = PropBlock<NF, CT>;
     constexpr int KS = 2 * NF;
-    __shared__ uint4 img[2 * KS * 2 * 64];
+    __shared__ uint4 img[PB::IMG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int colbase = blockIdx.x * 64;
+    const int colbase = blockIdx.x * 32 * CT;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
     float* __restrict__ D0 = p.base;
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     for (int s = 0; s < 2; ++s) {
         float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
         const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
-        int opq = 0;                                   // opaque zero: keeps the 32 element offsets below from
+        int opq = 0;                                   // opaque zero: keeps the element offsets below from
         asm volatile("" : "+s"(opq));                  // being hoisted out of the support loop (64 VGPRs)
         const int ldi = (int)p.ld + opq;
         uint4 ah[KS], al[KS];
@@ -310,15 +340,10 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         if (s > 0) __syncthreads();                    // previous image fully consumed
         PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
         __syncthreads();
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        f32x16 acc[CT];
         PB::mma(img, ah, al, acc, lane);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            __builtin_amdgcn_sched_barrier(0);         // keep the 32 in-flight loads of one tile from piling up
+        for (int t = 0; t < CT; ++t) {
             const int col = colbase + 32 * t + cperm;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -336,21 +361,15 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         __syncthreads();
         PB::to_img(img, acc, w, lane);
         __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
         PB::mma(img, ah, al, acc, lane);
-        // dP[0] += S_s^T d1t_s : read-modify-write by the same lane for both supports (fixed order)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < CT; ++t) {
             const int col = colbase + 32 * t + cperm;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
                 if (r < p.N && col < p.ncols) {
-                    const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
+                    const int off = r * ldi + col;
                     D0[off] = D0[off] + acc[t][v];
                 }
             }
@@ -358,27 +377,43 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     }
 }
 
-#define MCRN_NF_SWITCH(KERN, GRID, P)                                                        \
+#define MCRN_NF_SWITCH(KERN, CT_, GRID, P)                                                   \
     switch (NF) {                                                                            \
-        case 1: hipLaunchKernelGGL(KERN<1>, GRID, dim3(64), 0, st, P); break;                \
-        case 2: hipLaunchKernelGGL(KERN<2>, GRID, dim3(128), 0, st, P); break;               \
-        case 3: hipLaunchKernelGGL(KERN<3>, GRID, dim3(192), 0, st, P); break;               \
-        case 4: hipLaunchKernelGGL(KERN<4>, GRID, dim3(256), 0, st, P); break;               \
-        case 5: hipLaunchKernelGGL(KERN<5>, GRID, dim3(320), 0, st, P); break;               \
-        case 6: hipLaunchKernelGGL(KERN<6>, GRID, dim3(384), 0, st, P); break;               \
-        case 7: hipLaunchKernelGGL(KERN<7>, GRID, dim3(448), 0, st, P); break;               \
-        default: hipLaunchKernelGGL(KERN<8>, GRID, dim3(512), 0, st, P); break;              \
+        case 1: hipLaunchKernelGGL((KERN<1, CT_>), GRID, dim3(64), 0, st, P); break;         \
+        case 2: hipLaunchKernelGGL((KERN<2, CT_>), GRID, dim3(128), 0, st, P); break;        \
+        case 3: hipLaunchKernelGGL((KERN<3, CT_>), GRID, dim3(192), 0, st, P); break;        \
+        case 4: hipLaunchKernelGGL((KERN<4, CT_>), GRID, dim3(256), 0, st, P); break;        \
+        case 5: hipLaunchKernelGGL((KERN<5, CT_>), GRID, dim3(320), 0, st, P); break;        \
+        case 6: hipLaunchKernelGGL((KERN<6, CT_>), GRID, dim3(384), 0, st, P); break;        \
+        case 7: hipLaunchKernelGGL((KERN<7, CT_>), GRID, dim3(448), 0, st, P); break;        \
+        default: hipLaunchKernelGGL((KERN<8, CT_>), GRID, dim3(512), 0, st, P); break;       \
     }
+// column tiles per workgroup: minimise (rounds over 256 CUs) x (work per workgroup)
+static inline int pick_ct(int ncols, int ny) {
+    const long long b2 = (long long)((ncols + 63) / 64) * ny, b1 = (long long)((ncols + 31) / 32) * ny;
+    const long long t2 = ((b2 + 255) / 256) * 2, t1 = ((b1 + 255) / 256) * 1;
+    return t1 < t2 ? 1 : 2;
+}
 static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     const int NF = (p.N + 31) / 32;
-    dim3 grid((p.ncols + 63) / 64, 2);
-    MCRN_NF_SWITCH(prop2_fwd_kernel, grid, p)
+    if (pick_ct(p.ncols, 2) == 1) {
+        dim3 grid((p.ncols + 31) / 32, 2);
+        MCRN_NF_SWITCH(prop2_fwd_kernel, 1, grid, p)
+    } else {
+        dim3 grid((p.ncols + 63) / 64, 2);
+        MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p)
+    }
     return hipGetLastError();
 }
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     const int NF = (p.N + 31) / 32;
-    dim3 grid((p.ncols + 63) / 64, 1);
-    MCRN_NF_SWITCH(prop2_bwd_kernel, grid, p)
+    if (pick_ct(p.ncols, 1) == 1) {
+        dim3 grid((p.ncols + 31) / 32, 1);
+        MCRN_NF_SWITCH(prop2_bwd_kernel, 1, grid, p)
+    } else {
+        dim3 grid((p.ncols + 63) / 64, 1);
+        MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p)
+    }
     return hipGetLastError();
 }
 

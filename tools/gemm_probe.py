@@ -21,8 +21,10 @@ def run(M, N, K, tA, tB, cfg, reps=30):
     e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / reps
 
+if __name__ != "__main__":
+    shapes = []
 CFG = ["128x128", "64x128", "128x64", "64x64", "32x128", "256x64", "64x256", "auto"]
-shapes = [("prop207", 207, 8448, 207, 0, 0), ("prop207_K414", 207, 8448, 414, 0, 0), ("prop207_K32", 207, 8448, 32, 0, 0),
+shapes = [] if __name__ != "__main__" else [("prop207", 207, 8448, 207, 0, 0), ("prop207_K414", 207, 8448, 414, 0, 0), ("prop207_K32", 207, 8448, 32, 0, 0),
           ("M256", 256, 8448, 207, 0, 0), ("M128", 128, 8448, 207, 0, 0), ("N4224", 207, 4224, 207, 0, 0),
           ("wp", 13248, 128, 680, 0, 0), ("dgrad", 13248, 680, 256, 0, 1), ("dS", 207, 207, 8448, 0, 1),
           ("big1843", 1843, 2112, 1843, 0, 0), ("sq4096", 4096, 4096, 4096, 0, 0)]
