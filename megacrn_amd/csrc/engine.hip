@@ -620,7 +620,7 @@ struct ModelPlan {
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
     float *dWq_s, *dMem_s, *dWp_s;
-    float *part;
+    float *part, *part2;
     size_t total;
 };
 
@@ -685,6 +685,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.dWp_s = b.take<float>((size_t)NSLAB_W * od * Hd);
     int Tm = d->T_in > d->T_out ? d->T_in : d->T_out;
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
+    P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.total = (b.off + 255) & ~(size_t)255;
 }
 
@@ -698,17 +699,39 @@ static Sup model_sup(const ModelPlan& P, int N) {
     return u;
 }
 
+// q = h Wq and sc = q Mem^T on the MFMA GEMM, then one light row kernel (softmax, top-2, value, outputs)
 static int memory_fwd_launch(const float* h, long long ldh, const float* Wq, const float* Mem, int B, int N,
-                             int H, int M, int D, float* q_rows, float* att_rows, int* ind_rows, float* s0,
-                             long long lds0, float* val, float* q, float* pos, float* neg, int* ind_bnc,
+                             int H, int M, int D, float* q_rows, float* att_rows, float* sc_rows, int* ind_rows,
+                             float* s0, long long lds0, float* val, float* q, float* pos, float* neg, int* ind_bnc,
                              hipStream_t st) {
-    const int nt = 64;
-    size_t shm = ((size_t)H * D + (size_t)M * D + (size_t)(D + M) * nt) * sizeof(float);
-    if (shm > 160 * 1024) FAIL("memory head too large for LDS (H*D + M*D + 64*(D+M) floats = %zu bytes)", shm);
-    if (shm > 64 * 1024)
-        CK(hipFuncSetAttribute((const void*)k_memory_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    LAUNCH(k_memory_fwd, dim3(cdiv((long long)N * B, nt)), dim3(nt), shm, st, h, ldh, Wq, Mem, B, N, H, M, D,
-           q_rows, att_rows, ind_rows, s0, lds0, val, q, pos, neg, ind_bnc);
+    const long long R = (long long)N * B;
+    // the top-2 prototype choice is discrete: evaluate query and scores in exact fp32 so that near-ties
+    // resolve like the reference's fp32 path (the bf16x3 error of 1e-5 would flip some of them)
+    const int saved_prec = g_precision;
+    g_precision = MCRN_F32;
+    {
+        GemmP p = gp();
+        p.M = (int)R; p.N = D; p.K = H;
+        p.A[0] = h; p.am = plain(ldh); p.ak = plain(1);
+        p.B[0] = Wq; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = q_rows; p.cm = plain(D); p.cn = plain(1);
+        const int rc_ = gemm(p, true, false, 0, ROLE_MISC, st);
+        if (rc_) { g_precision = saved_prec; return rc_; }
+    }
+    {   // raw scores (sc_rows is scratch; the backward pass reuses it for d(score))
+        GemmP p = gp();
+        p.M = (int)R; p.N = M; p.K = D;
+        p.A[0] = q_rows; p.am = plain(D); p.ak = plain(1);
+        p.B[0] = Mem; p.bk = plain(1); p.bn = plain(D);
+        p.C[0] = sc_rows; p.cm = plain(M); p.cn = plain(1);
+        const int rc_ = gemm(p, true, true, 0, ROLE_MISC, st);
+        g_precision = saved_prec;
+        CKI(rc_);
+    }
+    int nb = cdiv(R, 4);
+    if (nb > 4096) nb = 4096;
+    LAUNCH(k_memory_rows, dim3(nb), dim3(256), 0, st, (const float*)q_rows, (const float*)sc_rows, Mem, h, ldh, B, N, H,
+           M, D, att_rows, ind_rows, s0, lds0, val, q, pos, neg, ind_bnc);
     return 0;
 }
 static int memory_bwd_rows_launch(const float* dval_rows, long long ldv, int c0, const float* dval_bnc,
@@ -785,7 +808,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                           we, P.Zenc + (t + 1) * se.ZT, se.Cp, st));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
-                          P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
+                          P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
     // ---- decoder (:181-192)
     if (yd > 0) {
         CKI(fill_cols(P.Zdec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, st));
@@ -840,6 +863,17 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(cell_bwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                           wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dP, P.dQ, P.dacc_d, P.dxin_d, st));
     }
+    // Decoder weight/bias/projection gradients depend only on the finished decoder BPTT: run them on the
+    // helper stream so they overlap the memory-head and encoder backward below (joined before the adjacency
+    // backward).  Tuning / profiling runs keep them in-line.
+    hipStream_t ws_ = st;
+    float* part_ = P.part;
+    if (g_use_side && !g_tuning && g_prof.role < 0) {
+        CKI(side_init());
+        CK(hipEventRecord(g_side.ready[0], st));
+        CK(hipStreamWaitEvent(g_side.st, g_side.ready[0], 0));
+        ws_ = g_side.st; part_ = P.part2; g_side.any = true;
+    }
     {   // proj grads: dWp[j][c] = sum_{t,r} dgo[t][r][j] * h'_t[r][c]  (h'_t lives in Zdec[t+1])
         GemmP q = gp();
         q.M = od; q.N = Hd; q.K = (int)(To * R);
@@ -847,17 +881,17 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         q.B[0] = P.Zdec + sd.ZT; q.bk = two((int)R, sd.ZT, sd.Cp); q.bk_hi[0] = sd.ZT; q.bn = plain(1);
         q.C[0] = P.dWp_s; q.Cin[0] = P.dWp_s; q.cm = plain(Hd); q.cn = plain(1);
         q.beta = 1.f; q.slab = (long long)od * Hd;
-        CKI(gemm(q, false, false, NSLAB_W, ROLE_MISC, st));
-        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, st, g->proj_w, (const float*)P.dWp_s, NSLAB_W,
+        CKI(gemm(q, false, false, NSLAB_W, ROLE_MISC, ws_));
+        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, ws_, g->proj_w, (const float*)P.dWp_s, NSLAB_W,
                (long long)od * Hd, (long long)od * Hd, 0);
-        CKI(colsum(P.dgo, od, To * R, od, P.part, g->proj_b, 0, st));
+        CKI(colsum(P.dgo, od, To * R, od, part_, g->proj_b, 0, ws_));
     }
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], st));
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], st));
-    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, st));
-    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, st));
-    CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, P.part, g->dec_gate_b, 0, st));
-    CKI(colsum(P.dU_d, Hd, To * R, Hd, P.part, g->dec_update_b, 0, st));
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_));
+    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_));
+    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_));
+    CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
+    CKI(colsum(P.dU_d, Hd, To * R, Hd, part_, g->dec_update_b, 0, ws_));
     // ---- memory head backward: dacc_d = d[h_t | value]
     CKI(memory_bwd_rows_launch(P.dacc_d, Hd, H, d_hatt, d_query, P.att_rows, p->Memory, B, N, M, D, P.dval, P.dsc, P.dq, st));
     LAUNCH(k_copy2d, dim3(cdiv(R * H, 256)), dim3(256), 0, st, P.dacc_e, (long long)H, (const float*)P.dacc_d, (long long)Hd, R, H);
@@ -884,6 +918,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
            (long long)M * D, (long long)M * D, 0);
     if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
     if (d_neg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 1, d_neg, B, N, D);
+    CKI(side_join(st));
     return 0;
 }
 
@@ -1263,7 +1298,7 @@ int mcrn_memory_forward(int B, int N, int H, int M, int D, const float* h, const
     MemPlan P;
     plan_mem(B, N, H, M, D, (char*)ws, P);
     CKI(bnc_to_rows(P.h_rows, H, 0, H, h, B, N, st));
-    return memory_fwd_launch(P.h_rows, H, Wq, Mem, B, N, H, M, D, P.q_rows, P.att, P.ind, nullptr, 0, value, query,
+    return memory_fwd_launch(P.h_rows, H, Wq, Mem, B, N, H, M, D, P.q_rows, P.att, P.dsc, P.ind, nullptr, 0, value, query,
                              pos, neg, ind, st);
 }
 int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, const float* Mem, const float* Wq,

@@ -271,6 +271,52 @@ __global__ void k_memory_fwd(const float* __restrict__ h, long long ldh, const f
     if (s0) for (int c = 0; c < H; ++c) s0[r * lds0 + c] = hr[c];
 }
 
+// memory head, row part after the GEMMs q = h Wq and sc = q Mem^T: softmax over M, top-2, value = att Mem,
+// all outputs.  One wave per row: lanes over M for the softmax, lanes over D for the value / copies.
+__global__ void k_memory_rows(const float* __restrict__ q_rows, const float* __restrict__ sc_rows,
+                              const float* __restrict__ Mem, const float* __restrict__ h, long long ldh,
+                              int B, int N, int H, int M, int D, float* __restrict__ att_rows,
+                              int* __restrict__ ind_rows, float* __restrict__ s0, long long lds0,
+                              float* __restrict__ val_bnc, float* __restrict__ q_bnc, float* __restrict__ pos_bnc,
+                              float* __restrict__ neg_bnc, int* __restrict__ ind_bnc) {
+    const long long R = (long long)N * B;
+    const int wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += (long long)gridDim.x * wpb) {
+        // softmax over M (M <= 64 handled in one pass per lane; larger M loops)
+        float mx = -3.4e38f;
+        for (int m = lane; m < M; m += 64) mx = fmaxf(mx, sc_rows[r * M + m]);
+        mx = wave_max(mx);
+        float den = 0.f;
+        for (int m = lane; m < M; m += 64) den += expf(sc_rows[r * M + m] - mx);
+        den = wave_sum(den);
+        const float inv = 1.f / den;
+        // top-2 (largest first, lowest index on ties): every lane scans, M is small
+        int i0 = 0, i1 = -1; float b0 = -1.f, b1 = -1.f;
+        for (int m = 0; m < M; ++m) {
+            const float a = expf(sc_rows[r * M + m] - mx) * inv;
+            if (a > b0) { b1 = b0; i1 = i0; b0 = a; i0 = m; }
+            else if (a > b1) { b1 = a; i1 = m; }
+            if (lane == 0) att_rows[r * M + m] = a;
+        }
+        if (i1 < 0) i1 = i0;
+        const int n = (int)(r / B), b = (int)(r % B);
+        const long long o = ((long long)b * N + n) * D;
+        if (lane == 0) {
+            ind_rows[r * 2] = i0; ind_rows[r * 2 + 1] = i1;
+            if (ind_bnc) { ind_bnc[((long long)b * N + n) * 2] = i0; ind_bnc[((long long)b * N + n) * 2 + 1] = i1; }
+        }
+        for (int d = lane; d < D; d += 64) {
+            float v = 0.f;
+            for (int m = 0; m < M; ++m) v += (expf(sc_rows[r * M + m] - mx) * inv) * Mem[m * D + d];
+            const float qq = q_rows[r * D + d];
+            val_bnc[o + d] = v; q_bnc[o + d] = qq;
+            pos_bnc[o + d] = Mem[i0 * D + d]; neg_bnc[o + d] = Mem[i1 * D + d];
+            if (s0) s0[r * lds0 + H + d] = v;
+        }
+        if (s0) for (int c = lane; c < H; c += 64) s0[r * lds0 + c] = h[r * ldh + c];
+    }
+}
+
 // per row: datt = dval Mem^T ; dsc = att*(datt - sum(att*datt)) ; dq = dsc Mem + dq_ext
 // dval = dval_rows[r*ldv + c0 + d] (nullable) + dval_bnc (nullable)
 __global__ void k_memory_bwd_rows(const float* __restrict__ dval_rows, long long ldv, int c0,

@@ -22,3 +22,12 @@ def relerr(a, b):
     b = np.asarray(b, np.float64)
     den = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / den)
+
+
+def proto_mismatch_frac(got, want):
+    """pos/neg are gathers Memory[top-k index]: a discrete choice.  Fraction of (b, n) rows whose prototype
+    differs from the reference (near-ties between attention scores may legitimately resolve differently)."""
+    got = np.asarray(got, np.float64).reshape(-1, got.shape[-1])
+    want = np.asarray(want, np.float64).reshape(-1, want.shape[-1])
+    bad = np.abs(got - want).max(axis=1) > 1e-6 * max(np.abs(want).max(), 1e-30)
+    return float(bad.mean())
