@@ -62,6 +62,23 @@ def alg_flops_forward(cfg, B):
     return float(f)
 
 
+def pmc_traffic(config_name, dtype, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
+    (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 per
+    MI355X_MICROARCH.md).  None when no profile of this config is committed."""
+    path = os.path.join(ROOT, "profiles", "r1", f"traffic_{config_name}.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    key = "prop2_fwd_kernel" if (N <= 256 and dtype == "bf16x3") else "true, false, 1>"
+    tot = n = 0
+    for k, v in d.items():
+        if key in k:
+            tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(cfg, sample_B, steps):
     """The numpy oracle (a port of the reference CPU path) timed on this host, bounded sample."""
     from oracle import megacrn_oracle as O
@@ -72,12 +89,15 @@ def cpu_baseline(cfg, sample_B, steps):
     yc = rng.random((sample_B, T, N, 1)).astype(np.float32)
     y = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
     opt = O.Adam(P)
-    O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
-    t = time.perf_counter()
-    for s in range(steps):
-        O.train_step(P, opt, x, yc, y, [s % 2 == 0] * T, SC_MEAN, SC_STD)
-    dt = time.perf_counter() - t
-    return sample_B * steps / dt, dt
+    from threadpoolctl import threadpool_limits
+    nthr = min(32, os.cpu_count() or 1)      # more BLAS threads than this only slows these small matrices
+    with threadpool_limits(limits=nthr):
+        O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
+        t = time.perf_counter()
+        for s in range(steps):
+            O.train_step(P, opt, x, yc, y, [s % 2 == 0] * T, SC_MEAN, SC_STD)
+        dt = time.perf_counter() - t
+    return sample_B * steps / dt, dt, nthr
 
 
 def main():
@@ -157,12 +177,12 @@ def main():
         torch.cuda.synchronize()
         check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
         ach = af.value / (ms.value * 1e-3)
-        kname = ("mcrn::prop_small_kernel<NF>" if cfg["N"] <= 256 and dtype == "bf16x3" else
+        kname = ("mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 256 and dtype == "bf16x3" else
                  "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
         roof = {"bound": "mfma", "kernel": kname + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
                 "achieved": round(ach / 1e12, 3), "peak": round(PEAK[dtype] / 1e12, 1), "unit": "TFLOP/s",
-                "frac": round(ach / PEAK[dtype], 5), "traffic": None,
-                "note": "achieved = algorithmic fp32 flops (2 supports x 2 N^2 B C per launch) / HIP-event kernel time"
+                "frac": round(ach / PEAK[dtype], 5), "traffic": pmc_traffic(args.config, dtype, cfg["N"]),
+                "note": "achieved = algorithmic fp32 flops (2 N^2 B C per support and hop) / HIP-event kernel time; traffic = corrected PMC HBM bytes per launch (profiles/r1)"
                         + ("; bf16x3 issues 3 bf16 MFMAs per product, ceiling 833 TF" if dtype == "bf16x3" else ""),
                 "avg_launch_us": round(1e3 * ms.value / n.value, 3), "launches": n.value,
                 "alg_flops_per_launch": af.value / n.value}
@@ -170,12 +190,12 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sample_B = max(1, B // 8)
-        v, secs = cpu_baseline(cfg, sample_B, 4)
-        cpu = {"value": round(v, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"oracle/megacrn_oracle.py (numpy, BLAS threads={os.cpu_count()}) full train step on "
-                         f"{sample_B} of the {B} samples of the same {cfg['label']} workload, 4 timed steps "
-                         f"after 1 warm-up ({secs:.1f} s)"}
+        sample_B = max(1, B // 4)
+        v, secs, nthr = cpu_baseline(cfg, sample_B, 3)
+        cpu = {"value": round(v, 3), "unit": "samples/s", "cores": nthr, "kind": "port",
+               "sample": f"oracle/megacrn_oracle.py (numpy, {nthr} BLAS threads of {os.cpu_count()} host cores) full "
+                         f"train step on {sample_B} of the {B} samples of the same {cfg['label']} workload, 3 timed "
+                         f"steps after 1 warm-up ({secs:.1f} s)"}
 
     if rank == 0:
         gb = B * world
