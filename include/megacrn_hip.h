@@ -191,6 +191,8 @@ int mcrn_autotune_entries(void);
 int mcrn_autotune_clear(void);
 /* tuning hook: force GEMM tile configuration 0..6 for every launch (-1 = automatic) */
 int mcrn_set_gemm_cfg(int cfg);
+/* ablation bits for the GEMM main loop (results are WRONG when non-zero; tools/ablate.py only) */
+int mcrn_set_debug(int bits);
 int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);
 
 #ifdef __cplusplus

@@ -8,6 +8,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede loading the .so: PyTorch bundles its own libamdhip64; loading ours first
+#                     would bind the system HIP runtime and leave two runtimes in the process (launches then fail
+#                     with "no ROCm-capable device").  With torch loaded, the soname resolves to the same runtime.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmegacrn_hip.so")
 
@@ -18,7 +22,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
+    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
 ]
 
 
@@ -109,6 +113,8 @@ def _load():
     lib.mcrn_model_autotune.argtypes = [C.POINTER(Dims), vp, sz, vp]
     lib.mcrn_autotune_entries.restype = i
     lib.mcrn_autotune_clear.restype = i
+    lib.mcrn_set_debug.restype = i
+    lib.mcrn_set_debug.argtypes = [i]
     lib.mcrn_set_gemm_cfg.restype = i
     lib.mcrn_set_gemm_cfg.argtypes = [i]
     lib.mcrn_prof_end.restype = i

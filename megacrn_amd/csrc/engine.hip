@@ -26,6 +26,7 @@ namespace mcrn {
 
 GemmStats g_gemm_stats = {0, 0.0};
 int g_force_cfg = -1;
+int g_debug = 0;
 static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch
 static char g_err[512] = "";
 static int g_launches = 0;
@@ -51,6 +52,7 @@ static int g_launches = 0;
     } while (0)
 #define LAUNCH(kern, grid, blk, shm, st, ...)                                                 \
     do {                                                                                      \
+        (void)hipGetLastError(); /* drop stale sticky errors of other runtime users (e.g. torch) */ \
         hipLaunchKernelGGL(kern, grid, blk, shm, st, __VA_ARGS__);                            \
         ++g_launches;                                                                         \
         CK(hipGetLastError());                                                                \
@@ -1023,6 +1025,7 @@ int mcrn_version(void) { return 100; }
 int mcrn_last_launch_count(void) { return g_launches; }
 
 int mcrn_set_gemm_cfg(int cfg) { g_force_cfg = cfg; return 0; }
+int mcrn_set_debug(int bits) { g_debug = bits; return 0; }
 
 int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream) {
     CKI(check_dims(d));

@@ -176,19 +176,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const float* __restrict__ Bb = p.B[batch];
     const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
     const bool afast = (p.vec & 1) != 0, bfast = (p.vec & 2) != 0;
+    const int dbg = p.vec >> 8;      // ablation knob (tools/ablate.py): 1 = no MFMA, 2 = no global loads, 4 = no convert/LDS store, 8 = no barrier
 
     TA ta;
     TB tb;
     ta.init(Ab, tid, m_blk, p.M, p.am, kbeg, p.ak.inner, akhi, p.ak.lo);
     tb.init(Bb, tid, n_blk, p.N, p.bn, kbeg, p.bk.inner, bkhi, p.bk.lo);
 
-    f32x16 acc[FM][FN];
+    // small tiles (<= 2 fragments per wave) keep the two low-order products in their own accumulators;
+    // larger ones share `acc` (the product-outer loop order already spaces dependent MFMAs FM*FN apart)
+    constexpr bool SPLIT_ACC = FM * FN <= 2;
+    f32x16 acc[FM][FN], accA_[SPLIT_ACC ? FM : 1][SPLIT_ACC ? FN : 1], accB_[SPLIT_ACC ? FM : 1][SPLIT_ACC ? FN : 1];
+    f32x16 (&accA)[FM][FN] = *reinterpret_cast<f32x16 (*)[FM][FN]>(SPLIT_ACC ? &accA_ : (void*)&acc);
+    f32x16 (&accB)[FM][FN] = *reinterpret_cast<f32x16 (*)[FM][FN]>(SPLIT_ACC ? &accB_ : (void*)&acc);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+            for (int v = 0; v < 16; ++v) {
+                acc[i][j][v] = 0.f;
+                if (SPLIT_ACC) { accA[i][j][v] = 0.f; accB[i][j][v] = 0.f; }
+            }
 
     // Software pipeline: tile t is computed from LDS stage t&1 while tile t+1 sits in registers (converted
     // and stored to the other LDS stage at the end of the iteration) and tile t+2 is in flight from
@@ -230,37 +239,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
                 bh[j] = __builtin_bit_cast(bf16x8, sBh[o]);                                         \
                 bl[j] = __builtin_bit_cast(bf16x8, sBl[o]);                                         \
             }                                                                                       \
+            /* three independent accumulator chains (one per split product) so no MFMA waits on the previous one */ \
             _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
-                _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+                    accA[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], accA[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+                    accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], accB[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
-                }                                                                                   \
         }                                                                                           \
     } while (0)
 
-    typename TA::Regs ra0, ra1;
-    typename TB::Regs rb0, rb1;
-    MCRN_LOAD_TILE(ra0, rb0);                                // tile 0
-    if (nt > 1) MCRN_LOAD_TILE(ra1, rb1);                    // tile 1
-    MCRN_STORE_TILE(ra0, rb0, 0);
+    // register stages: NS tiles are in flight between "requested" and "stored to LDS".  Bytes in flight per CU
+    // set the achievable fill bandwidth (Little's law: ~2 us loaded latency), so the small tiles, which have
+    // registers to spare, run 4 stages deep; the big ones 2.
+    constexpr int NS = (BM + BN <= 128) ? 4 : 2;
+    typename TA::Regs ra[NS];
+    typename TB::Regs rb[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (i < nt) MCRN_LOAD_TILE(ra[i], rb[i]);            // tiles 0 .. NS-1
+    MCRN_STORE_TILE(ra[0], rb[0], 0);
     __syncthreads();
-    for (int t = 0; t < nt; t += 2) {
-        // even tile t: registers set 0 is free (tile t is in LDS stage 0) -> request tile t+2 into it
-        if (t + 2 < nt) MCRN_LOAD_TILE(ra0, rb0);
-        MCRN_COMPUTE(0);
-        if (t + 1 < nt) MCRN_STORE_TILE(ra1, rb1, 1);        // tile t+1 -> stage 1
-        __syncthreads();
-        if (t + 1 >= nt) break;
-        // odd tile t+1
-        if (t + 3 < nt) MCRN_LOAD_TILE(ra1, rb1);
-        MCRN_COMPUTE(1);
-        if (t + 2 < nt) MCRN_STORE_TILE(ra0, rb0, 0);        // tile t+2 -> stage 0
-        __syncthreads();
+    for (int t0 = 0; t0 < nt; t0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {                       // static register-set indices: set = tile % NS
+            const int t = t0 + u;
+            if (t >= nt) break;
+            if (t + NS < nt && !(dbg & 2)) MCRN_LOAD_TILE(ra[u], rb[u]);   // set u held tile t (already in LDS) -> tile t+NS
+            // convert + store tile t+1 into the other LDS stage; independent of the MFMA block below, emitted
+            // first so the scheduler can interleave its VALU/DS work with the matrix instructions
+            if (t + 1 < nt && !(dbg & 4)) {
+                if (u & 1) MCRN_STORE_TILE(ra[(u + 1) % NS], rb[(u + 1) % NS], 0);
+                else MCRN_STORE_TILE(ra[(u + 1) % NS], rb[(u + 1) % NS], 1);
+            }
+            if (!(dbg & 1)) { if (u & 1) MCRN_COMPUTE(1); else MCRN_COMPUTE(0); }   // NS is even: LDS stage = t & 1 = u & 1
+            if (!(dbg & 8)) __syncthreads();
+        }
     }
 #undef MCRN_LOAD_TILE
 #undef MCRN_STORE_TILE
 #undef MCRN_COMPUTE
+    if (SPLIT_ACC) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] += accA[i][j][v] + accB[i][j][v];
+    }
     gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kq, n_blk + wn * WN + l31);
 }
 
@@ -276,6 +305,7 @@ static inline hipError_t launch_one_x3(const GemmP& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    (void)hipGetLastError();
     hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
@@ -325,7 +355,7 @@ static inline bool fast_ok(bool kc, const float* const* bases, int nbatch, const
 static inline hipError_t launch_gemm_x3(GemmP p, bool akc, bool bkc, int max_split, int role, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     const int cfg = choose_cfg(p, max_split, 32);
-    p.vec = 0;
+    p.vec = g_debug << 8;
     if (fast_ok(akc, p.A, p.nbatch, p.am, p.ak, p.ak_hi)) p.vec |= 1;
     if (fast_ok(bkc, p.B, p.nbatch, p.bn, p.bk, p.bk_hi)) p.vec |= 2;
     return launch_role_x3(p, akc, bkc, role, cfg, st);

@@ -280,10 +280,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 struct GemmStats { long long launches; double flops; };
 extern GemmStats g_gemm_stats;
 extern int g_force_cfg;   // >= 0: force this tile configuration (tuning sweeps)
+extern int g_debug;       // ablation bits for the bf16x3 kernel (0 in production)
 
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
+    (void)hipGetLastError();
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -395,6 +395,7 @@ static inline int pick_ct(int ncols, int ny) {
     return t1 < t2 ? 1 : 2;
 }
 static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
+    (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     if (pick_ct(p.ncols, 2) == 1) {
         dim3 grid((p.ncols + 31) / 32, 2);
@@ -406,6 +407,7 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     return hipGetLastError();
 }
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
+    (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     if (pick_ct(p.ncols, 1) == 1) {
         dim3 grid((p.ncols + 31) / 32, 1);
@@ -427,10 +429,12 @@ static inline size_t sfrag_uint4(int N) {
 static inline hipError_t launch_sfrag(const float* S, long long ldS, int N, int transpose, uint4* out, hipStream_t st) {
     const int NF = (N + 31) / 32;
     const int tot = NF * 2 * NF * 64;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_sfrag_build, dim3((tot + 255) / 256), dim3(256), 0, st, S, ldS, N, NF, transpose, out);
     return hipGetLastError();
 }
 static inline hipError_t launch_prop_small(const PropP& p, int nbatch, hipStream_t st) {
+    (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     dim3 grid((p.ncols + 63) / 64, nbatch);
     switch (NF) {
