@@ -15,6 +15,7 @@
 #include <string.h>
 #include <math.h>
 #include <map>
+#include <stdlib.h>
 
 #include "../../include/megacrn_hip.h"
 #include "gemm_f32.h"
@@ -112,17 +113,23 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
             }
             int best = -1;
             float best_ms = 1e30f;
-            for (int c = 0; c < NCFG; ++c) {
-                g_force_cfg = c;
-                CKI(launch_any(p, akc, bkc, max_split, role, st));            // warm-up
-                CK(hipEventRecord(g_tune_ev[0], st));
-                for (int r = 0; r < 3; ++r) CKI(launch_any(p, akc, bkc, max_split, role, st));
-                CK(hipEventRecord(g_tune_ev[1], st));
-                CK(hipEventSynchronize(g_tune_ev[1]));
-                float ms = 0;
-                CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
-                if (ms < best_ms) { best_ms = ms; best = c; }
+            float cfg_ms[NCFG];
+            for (int c = 0; c < NCFG; ++c) cfg_ms[c] = 1e30f;
+            for (int round = 0; round < 3; ++round) {          // min over 3 rounds of 6 launches: robust to noise
+                for (int c = 0; c < NCFG; ++c) {
+                    g_force_cfg = c;
+                    CKI(launch_any(p, akc, bkc, max_split, role, st));            // warm-up
+                    CK(hipEventRecord(g_tune_ev[0], st));
+                    for (int r = 0; r < 6; ++r) CKI(launch_any(p, akc, bkc, max_split, role, st));
+                    CK(hipEventRecord(g_tune_ev[1], st));
+                    CK(hipEventSynchronize(g_tune_ev[1]));
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                    if (ms < cfg_ms[c]) cfg_ms[c] = ms;
+                }
             }
+            for (int c = 0; c < NCFG; ++c)
+                if (cfg_ms[c] < best_ms) { best_ms = cfg_ms[c]; best = c; }
             g_tuned[key] = best;
             g_force_cfg = best;
         }
@@ -240,8 +247,10 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     float* dS;      // [2][nslab][N*ldS]
     int nslab;
     long long slab;
+    long long sup_stride;   // floats between the slab sets of support 0 and 1
+    bool defer;     // adjacency gradient is computed once per stack by ds_deferred_kernel
 };
-static int nslab_S(int N) { return N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1)); }
+static int nslab_S(int N) { return N <= 256 ? 64 : N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1)); }
 static const int NSLAB_W = 64;
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -365,6 +374,34 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
+    if (u.defer) {
+        // nothing here: d1t / e2 stay in this call's plane set and are consumed by the deferred launch
+    } else if (small && aligned16(X)) {   // output-stationary adjacency-gradient kernel (prop_small.h)
+        DsP q;
+        memset(&q, 0, sizeof q);
+        q.nseg = s.K == 3 ? 2 : 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.ldc = u.ldS; q.slab = u.slab;
+        for (int b = 0; b < 2; ++b) {
+            const long long g1 = 1 + b * (s.K - 1);
+            q.A[b][0] = dP + g1 * s.PS;       q.B[b][0] = X;                      // d1t x0^T
+            q.A[b][1] = dP + (g1 + 1) * s.PS; q.B[b][1] = X + g1 * s.PS;          // e2  x1^T
+            q.C[b] = u.dS + (long long)b * u.sup_stride;
+        }
+        const double ex = 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
+        hipStream_t ds_st = st;
+        if (side) {
+            CK(hipEventRecord(g_side.ready[buf], st));
+            CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
+            ds_st = g_side.st;
+        }
+        {
+            hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
+            MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st), ex, 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
+        }
+        if (side) {
+            CK(hipEventRecord(g_side.done[buf], g_side.st));
+            g_side.pending[buf] = true; g_side.any = true;
+        }
+    } else
     {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
         GemmP p = gp();
         const int nk = s.K == 3 ? 2 : 1;
@@ -377,7 +414,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             const long long g1 = 1 + b * (s.K - 1);
             p.A[b] = dP + g1 * s.PS; p.ak_hi[b] = s.PS;
             p.B[b] = X;              p.bk_hi[b] = g1 * s.PS;
-            p.C[b] = u.dS + (long long)b * u.nslab * u.slab;
+            p.C[b] = u.dS + (long long)b * u.sup_stride;
             p.Cin[b] = p.C[b];
         }
         if (side) {   // off the critical path: only sup_bwd_core (after all BPTT) consumes the slabs
@@ -618,6 +655,9 @@ struct ModelPlan {
     float *Zdec, *Ydec, *zr_d, *hc_d;
     float *q_rows, *att_rows; int* ind_rows;
     float *dP, *dQ;
+    float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
+    float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
+    bool defer_ds;
     float *dU_e, *dG_e, *dU_d, *dG_d;
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
@@ -645,7 +685,14 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.ldS = (N + 3) & ~3;
     P.nslabS = nslab_S(N);
     plan_sup(b, N, M, D, P.ldS, P.sup);
-    P.dS = b.take<float>((size_t)2 * P.nslabS * N * P.ldS);
+    P.defer_ds = false; P.ndef_d = P.ndef_e = 0;
+    {
+        // experimental (measured slower at METR-LA: the long deferred launch starves the critical path): opt-in
+        static const bool defer_env = getenv("MCRN_DEFER_DS") && atoi(getenv("MCRN_DEFER_DS")) == 1;
+        P.defer_ds = defer_env && N <= 256 && d->precision == MCRN_BF16X3 && (P.sd.ld % 4) == 0;
+        if (P.defer_ds) P.ndef_d = ds_deferred_chunks((int)P.sd.ld);
+    }
+    P.dS = b.take<float>((size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS);   // per support: [per-call split-K slabs | decoder deferred slabs]
     const Shp* sh[4] = {&P.se, &P.se, &P.sd, &P.sd};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) {
@@ -669,6 +716,8 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     size_t zmax = (size_t)(P.se.ZT > P.sd.ZT ? P.se.ZT : P.sd.ZT);
     P.dP = b.take<float>(zmax);
     P.dQ = b.take<float>(zmax);
+    P.dPall_e = P.dSdef = nullptr;
+    P.dPall_d = P.defer_ds ? b.take<float>((size_t)d->T_out * 2 * P.sd.ZT) : nullptr;
     P.dU_e = b.take<float>((size_t)d->T_in * R * H);
     P.dG_e = b.take<float>((size_t)d->T_in * R * 2 * H);
     P.dU_d = b.take<float>((size_t)d->T_out * R * Hd);
@@ -698,6 +747,8 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.Sf[0] = P.sup.frag[0]; u.Sf[1] = P.sup.frag[1]; u.Stf[0] = P.sup.frag[2]; u.Stf[1] = P.sup.frag[3];
     u.ldS = P.ldS;
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
+    u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
+    u.defer = false;
     return u;
 }
 
@@ -835,6 +886,25 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     return 0;
 }
 
+// one deferred adjacency-gradient launch for a cell stack: slabs [slab0, slab0 + chunks) of both supports
+static int ds_deferred(const ModelPlan& P, const Shp& s, int T, const float* dPall, const float* Yall,
+                       const float* Zall, int slab0, int N, hipStream_t st) {
+    DsDefP q;
+    memset(&q, 0, sizeof q);
+    const long long slab = (long long)N * P.ldS;
+    const long long sup_stride = (long long)(P.nslabS + P.ndef_d) * slab;
+    (void)slab0;
+    q.dPall = dPall; q.Xall[0] = Yall; q.Xall[1] = Zall;
+    q.slabs[0] = P.dS + (long long)P.nslabS * slab;
+    q.slabs[1] = P.dS + sup_stride + (long long)P.nslabS * slab;
+    q.slab = slab; q.PS = s.PS; q.ZT = s.ZT; q.ld = s.ld; q.ldc = P.ldS;
+    q.T = T; q.K = s.K; q.N = N; q.ncols = (int)s.ld;
+    const int nseg = s.K == 3 ? 2 : 1;
+    const double ex = (double)T * 2 * nseg * 2.0 * 2.0 * (double)N * N * (double)s.ld;
+    MCRN_PROF_WRAP(ROLE_DS, launch_ds_deferred(q, st), ex, (double)T * 2 * nseg * 2.0 * 2.0 * (double)N * N * (double)s.B * s.C);
+    return 0;
+}
+
 static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher,
                           const float* d_output, const float* d_hatt, const float* d_query, const float* d_pos,
                           const float* d_neg, char* ws, const mcrn_grads_t* g, hipStream_t st) {
@@ -847,13 +917,14 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     const long long R = se.R;
     Sup u = model_sup(P, N);
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
-    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * P.ldS * sizeof(float), st));
+    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
     for (int i = 0; i < 4; ++i)
         CK(hipMemsetAsync(P.dWs[i], 0, (size_t)(i < 2 ? se : sd).G * (i < 2 ? se : sd).Cp * Os[i] * NSLAB_W * sizeof(float), st));
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_W * od * Hd * sizeof(float), st));
-    // ---- decoder BPTT
+    // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
+    Sup ud = u; ud.defer = P.defer_ds;
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b};
     for (int t = To - 1; t >= 0; --t) {
         const bool last = t == To - 1;
@@ -862,8 +933,10 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
                p->proj_w, Hd, od, B, N, last ? (const float*)nullptr : (const float*)P.dacc_d, P.dhn_d,
                P.dgo + (long long)t * R * od);
-        CKI(cell_bwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
-                          wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dP, P.dQ, P.dacc_d, P.dxin_d, st));
+        CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
+                          wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd,
+                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dP,
+                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ, P.dacc_d, P.dxin_d, st));
     }
     // Decoder weight/bias/projection gradients depend only on the finished decoder BPTT: run them on the
     // helper stream so they overlap the memory-head and encoder backward below (joined before the adjacency
@@ -888,6 +961,10 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                (long long)od * Hd, (long long)od * Hd, 0);
         CKI(colsum(P.dgo, od, To * R, od, part_, g->proj_b, 0, ws_));
     }
+    if (P.defer_ds) {
+        hipStream_t st = ws_;
+        CKI(ds_deferred(P, sd, To, P.dPall_d, P.Ydec, P.Zdec, 0, N, st));
+    }
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_));
     CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_));
     CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_));
@@ -905,7 +982,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b};
     for (int t = Ti - 1; t >= 0; --t)
         CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
-                          P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dP, P.dQ, P.dacc_e, P.dxin_e, st));
+                          P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
+                          P.dP, P.dQ, P.dacc_e, P.dxin_e, st));
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
     CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st));
     CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st));
@@ -914,8 +992,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
     // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
     CKI(side_join(st));
-    CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS,
-                     P.dS + (long long)P.nslabS * u.slab, P.ldS, P.nslabS, u.slab, g->We1, g->We2, P.dMem_s, st));
+    CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
+                     P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st));
     LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_W,
            (long long)M * D, (long long)M * D, 0);
     if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
@@ -1184,7 +1262,7 @@ int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, co
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(wprep(W, P.Wf, P.Wd, s, O, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
     CKI(bnc_to_rows(P.Z, s.Cp, 0, C, x, B, N, st));
@@ -1204,7 +1282,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
@@ -1238,7 +1316,7 @@ int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, 
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(wprep(gate_w, P.Wf[0], P.Wd[0], s, 2 * H, st));
     CKI(wprep(update_w, P.Wf[1], P.Wd[1], s, H, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
@@ -1262,7 +1340,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));

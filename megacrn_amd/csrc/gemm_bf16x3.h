@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const float* __restrict__ Bb = p.B[batch];
     const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
     const bool afast = (p.vec & 1) != 0, bfast = (p.vec & 2) != 0;
-    const int dbg = p.vec >> 8;      // ablation knob (tools/ablate.py): 1 = no MFMA, 2 = no global loads, 4 = no convert/LDS store, 8 = no barrier
+#ifdef MCRN_ABLATE
+    const int dbg = p.vec >> 8;      // ablation knob (tools/ablate.py, -DMCRN_ABLATE builds only): 1 = no MFMA, 2 = no global loads, 4 = no convert/LDS store, 8 = no barrier
+#else
+    constexpr int dbg = 0;
+#endif
 
     TA ta;
     TB tb;

@@ -419,6 +419,263 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adjacency gradient for small graphs (N <= 256), output-stationary:
+//   dS[n][m] += sum_seg sum_k  A_seg[n][k] * B_seg[m][k]      (k = the B*Cp columns of a plane)
+// (dS = d1t x0^T + e2 x1^T).  The N x N result lives entirely in accumulators:
+// wave w owns output rows 32w.. and all NF column fragments (NF x 16 VGPRs), a workgroup owns one K-chunk
+// and adds its partial into its own slab (split-K, reduced later in a fixed order).  Both operands are
+// K-contiguous plane rows, so A- and B-fragments are the same load (32 bytes per lane) + bf16 split;
+// the B fragments of the NF waves are exchanged through a double-buffered LDS image.  Every converted
+// fragment feeds NF x 3 MFMAs (21 at N = 207) instead of 3 in the tiled GEMM: MFMA-bound by design.
+// ---------------------------------------------------------------------------------------------
+struct DsP {
+    const float* A[2][2];       // [support][segment]
+    const float* B[2][2];
+    float* C[2];                // slab 0 of the support; slab z at + z*slab
+    long long slab;
+    int nseg, N, ncols, kchunk; // kchunk multiple of 16
+    long long ld, ldc;
+};
+
+template <int NF>
+__global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
+    // LDS image of one 32-column panel of both operands, in MFMA fragment order:
+    //   img[op][frag j = row/32][ks = (k/16)&1][hi/lo][slot = row%32 + 32*((k/8)&1)] : 8 bf16 (k%8)
+    // filled with 8-byte granules (4 consecutive k) by threads that load coalesced float4s: 8 lanes cover
+    // one row's 128-byte panel line.
+    __shared__ uint4 img[2][NF][2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int sup = blockIdx.y, z = blockIdx.x;
+    const int kbeg = z * p.kchunk;
+    const int kend = min(p.ncols, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+    const int npan = (kend - kbeg + 31) >> 5;               // 32-column panels per segment
+    const int total = npan * p.nseg;
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+
+    // loader role of this thread: rows r0 + 8*NF*i (i < 4), column quad cq (4 floats) of the panel
+    const int cq = tid & 7, r0 = tid >> 3;                  // 8*NF rows per pass, 4 passes cover 32*NF rows
+    float4 va[4], vb[4];
+    auto fetch = [&](int pn) {
+        const int seg = pn / npan, pi = pn - seg * npan;
+        const int k = kbeg + 32 * pi + 4 * cq;
+        const bool kv = k < kend;                           // ncols % 4 == 0: a float4 is all-in or all-out
+        const float* __restrict__ A = p.A[sup][seg];
+        const float* __restrict__ B = p.B[sup][seg];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r0 + 8 * NF * i, p.N - 1);    // clamped rows only feed outputs that are not stored
+            va[i] = kv ? *reinterpret_cast<const float4*>(A + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[i] = kv ? *reinterpret_cast<const float4*>(B + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto publish = [&]() {
+        uint2* g = reinterpret_cast<uint2*>(&img[0][0][0][0][0]);
+        const int ks = cq >> 2, kq8 = (cq >> 1) & 1, half = cq & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 8 * NF * i;
+            const int fj = r >> 5, slot = (r & 31) + 32 * kq8;
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const float4 x = op ? vb[i] : va[i];
+                const unsigned h01 = cvt_pk_bf16(x.x, x.y), h23 = cvt_pk_bf16(x.z, x.w);
+                const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
+                const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
+                const int base = (((op * NF + fj) * 2 + ks) * 2) * 64;          // uint4 index of [op][fj][ks][hi][0]
+                g[(base + slot) * 2 + half] = make_uint2(h01, h23);
+                g[(base + 64 + slot) * 2 + half] = make_uint2(l01, l23);
+            }
+        }
+    };
+    fetch(0);
+    for (int pn = 0; pn < total; ++pn) {
+        publish();                                           // panel pn: registers -> LDS image
+        if (pn + 1 < total) fetch(pn + 1);                   // next panel's loads fly during the MFMA block
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][lane]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[0][w][ks][1][lane]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, img[1][j][ks][0][lane]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, img[1][j][ks][1][lane]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // image consumed before the next publish
+    }
+    float* __restrict__ C = p.C[sup] + (long long)z * p.slab;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int c = 32 * j + l31;
+        if (c >= p.N) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N) {
+                // no-return atomic: fire-and-forget instead of 112 dependent load-add-store round trips per lane.
+                // Still deterministic: this element of this slab is updated by exactly one workgroup per
+                // launch and launches are stream-ordered.
+                const long long off = (long long)r * p.ldc + c;
+                __hip_atomic_fetch_add(&C[off], acc[j][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st) {
+    (void)hipGetLastError();
+    const int NF = (p.N + 31) / 32;
+    int kc = ((p.ncols + nslab - 1) / nslab + 31) / 32 * 32;
+    if (kc < 64) kc = 64;
+    p.kchunk = kc;
+    dim3 grid((p.ncols + kc - 1) / kc, 2);
+    switch (NF) {
+        case 1: hipLaunchKernelGGL(ds_small_kernel<1>, grid, dim3(64), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(ds_small_kernel<2>, grid, dim3(128), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(ds_small_kernel<3>, grid, dim3(192), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(ds_small_kernel<4>, grid, dim3(256), 0, st, p); break;
+        case 5: hipLaunchKernelGGL(ds_small_kernel<5>, grid, dim3(320), 0, st, p); break;
+        case 6: hipLaunchKernelGGL(ds_small_kernel<6>, grid, dim3(384), 0, st, p); break;
+        case 7: hipLaunchKernelGGL(ds_small_kernel<7>, grid, dim3(448), 0, st, p); break;
+        default: hipLaunchKernelGGL(ds_small_kernel<8>, grid, dim3(512), 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deferred adjacency gradient (N <= 256): ONE launch per cell stack after its BPTT loop.
+// A workgroup owns a 64-column chunk and walks every time step, both AGCNs (update: planes of Y, gate:
+// planes of Z) and both segments (d1t x0^T, e2 x1^T), accumulating the whole N x N result of one support
+// in registers, and stores it exactly once into its own slab (plain stores: no atomics, no zero fill,
+// fixed summation order).  Per step this replaces 48 launches that each flushed a full N x N partial.
+// ---------------------------------------------------------------------------------------------
+struct DsDefP {
+    const float* dPall;          // [T][2 (0 = update AGCN, 1 = gate AGCN)][G planes]   gradient planes
+    const float* Xall[2];        // [0] = Y plane sets (update AGCN inputs), [1] = Z plane sets (gate), [T][G planes]
+    float* slabs[2];             // per support: slab z at + z*slab
+    long long slab, PS, ZT, ld, ldc;
+    int T, K, N, ncols;
+};
+
+template <int NF>
+__global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
+    __shared__ uint4 img[2][NF][2][2][64];                  // one 32-column panel of both operands (see ds_small)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int sup = blockIdx.y, z = blockIdx.x;
+    const int kbeg = z * 64;
+    const int kend = min(p.ncols, kbeg + 64);
+    const int npan = (kend - kbeg + 31) >> 5;               // 1 or 2 panels per (step, AGCN, segment)
+    const int nseg = p.K == 3 ? 2 : 1;
+    const int total = p.T * 2 * nseg * npan;
+    const long long g1 = 1 + (long long)sup * (p.K - 1);    // plane of S_s x / d1t of this support
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+
+    const int cq = tid & 7, r0 = tid >> 3;
+    float4 va[4], vb[4];
+    auto fetch = [&](int it) {
+        int q = it;
+        const int pi = q % npan; q /= npan;
+        const int seg = q % nseg; q /= nseg;
+        const int ag = q & 1, t = q >> 1;
+        const float* __restrict__ A = p.dPall + ((long long)t * 2 + ag) * p.ZT + (g1 + seg) * p.PS;         // d1t | e2
+        const float* __restrict__ B = p.Xall[ag] + (long long)t * p.ZT + (seg ? g1 * p.PS : 0);            // x0  | x1
+        const int k = kbeg + 32 * pi + 4 * cq;
+        const bool kv = k < kend;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r0 + 8 * NF * i, p.N - 1);
+            va[i] = kv ? *reinterpret_cast<const float4*>(A + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[i] = kv ? *reinterpret_cast<const float4*>(B + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto publish = [&]() {
+        uint2* g = reinterpret_cast<uint2*>(&img[0][0][0][0][0]);
+        const int ks = cq >> 2, kq8 = (cq >> 1) & 1, half = cq & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 8 * NF * i;
+            const int fj = r >> 5, slot = (r & 31) + 32 * kq8;
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const float4 x = op ? vb[i] : va[i];
+                const unsigned h01 = cvt_pk_bf16(x.x, x.y), h23 = cvt_pk_bf16(x.z, x.w);
+                const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
+                const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
+                const int base = (((op * NF + fj) * 2 + ks) * 2) * 64;
+                g[(base + slot) * 2 + half] = make_uint2(h01, h23);
+                g[(base + 64 + slot) * 2 + half] = make_uint2(l01, l23);
+            }
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < total; ++it) {
+        publish();
+        if (it + 1 < total) fetch(it + 1);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][lane]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[0][w][ks][1][lane]);
+            // product-outer order: the NF accumulators are independent chains
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, __builtin_bit_cast(bf16x8, img[1][j][ks][0][lane]), acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][1][lane]), acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][0][lane]), acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* __restrict__ C = p.slabs[sup] + (long long)z * p.slab;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int c = 32 * j + l31;
+        if (c >= p.N) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N) C[(long long)r * p.ldc + c] = acc[j][v];
+        }
+    }
+}
+static inline int ds_deferred_chunks(int ncols) { return (ncols + 63) / 64; }
+static inline hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st) {
+    (void)hipGetLastError();
+    const int NF = (p.N + 31) / 32;
+    dim3 grid(ds_deferred_chunks(p.ncols), 2);
+    switch (NF) {
+        case 1: hipLaunchKernelGGL(ds_deferred_kernel<1>, grid, dim3(64), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(ds_deferred_kernel<2>, grid, dim3(128), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(ds_deferred_kernel<3>, grid, dim3(192), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(ds_deferred_kernel<4>, grid, dim3(256), 0, st, p); break;
+        case 5: hipLaunchKernelGGL(ds_deferred_kernel<5>, grid, dim3(320), 0, st, p); break;
+        case 6: hipLaunchKernelGGL(ds_deferred_kernel<6>, grid, dim3(384), 0, st, p); break;
+        case 7: hipLaunchKernelGGL(ds_deferred_kernel<7>, grid, dim3(448), 0, st, p); break;
+        default: hipLaunchKernelGGL(ds_deferred_kernel<8>, grid, dim3(512), 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
 static inline bool prop_small_ok(int N, long long ld, int ncols) {
     return N <= 256 && (ncols % 4) == 0 && (ld % 4) == 0;
 }
