@@ -322,8 +322,10 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
 }
 
 // ---- weight pool with fused epilogue:  out = epi([Z planes] @ Wf + b)   (MegaCRN.py:26-27) ----
-static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP epi, hipStream_t st) {
+static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP epi, hipStream_t st,
+                  const uint4* img = nullptr) {
     GemmP p = epi;
+    if (img && g_precision == MCRN_BF16X3) { p.Bimg = img; p.bimg_n = (O + 3) & ~3; }
     p.M = (int)s.R; p.N = O; p.K = s.G * s.Cp;
     p.A[0] = Z; p.B[0] = Wf;
     p.am = plain(s.Cp); p.ak = two(s.Cp, s.PS, 1); p.ak_hi[0] = s.PS;
@@ -334,7 +336,7 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
-                         const float* X, float* dP, hipStream_t st, int buf = 0) {
+                         const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr) {
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
     {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
@@ -343,6 +345,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.A[0] = dY; p.am = plain(O); p.ak = plain(1);
         p.B[0] = Wd; p.bk = plain(1); p.bn = plain(O);
         p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
+        if (imgd && g_precision == MCRN_BF16X3) { p.Bimg = imgd; p.bimg_n = (s.G * s.Cp + 3) & ~3; }
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
@@ -489,7 +492,7 @@ static int colsum(const float* X, long long ld, long long rows, int C, float* pa
 static size_t colsum_part_floats(long long rows, int C) { return (size_t)cdiv(rows, COLSUM_CHUNK) * C; }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
-struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; };
+struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr; };
 
 static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* zr, float* hc,
                          const CellW& w, float* hnext, long long hnext_ld, hipStream_t st) {
@@ -497,12 +500,12 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
     GemmP e = gp();
     e.epi = EPI_GATE; e.C[0] = zr; e.bias = w.bg; e.hsrc = Z; e.hsrc_ld = s.Cp;
     e.out2 = Y; e.out2_ld = s.Cp; e.H = s.H;
-    CKI(wp_fwd(s, Z, w.Wf_g, 2 * s.H, e, st));
+    CKI(wp_fwd(s, Z, w.Wf_g, 2 * s.H, e, st, w.if_g));
     CKI(prop_fwd(s, u, Y, st));
     e = gp();
     e.epi = EPI_UPDATE; e.C[0] = hc; e.bias = w.bu; e.hsrc = Z; e.hsrc_ld = s.Cp; e.zr = zr;
     e.out2 = hnext; e.out2_ld = hnext_ld; e.H = s.H;
-    CKI(wp_fwd(s, Y, w.Wf_u, s.H, e, st));
+    CKI(wp_fwd(s, Y, w.Wf_u, s.H, e, st, w.if_u));
     return 0;
 }
 
@@ -511,9 +514,9 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st) {
     const long long RH = s.R * s.H;
     LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0));
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1));
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g));
     LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dP, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     return 0;
 }
@@ -634,9 +637,23 @@ static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long l
     LAUNCH(k_zero_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, dst, dst_t, Cp, c0, c1, R, T);
     return 0;
 }
-static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st) {
+static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st, uint4* imgf = nullptr,
+                 uint4* imgd = nullptr) {
     long long tot = (long long)s.G * s.Cp * O;
     LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O);
+    if (imgf && g_precision == MCRN_BF16X3) {
+        const int Kp = s.G * s.Cp;
+        {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
+            const int npad = (O + 3) & ~3;
+            const long long n = (long long)((Kp + 31) / 32) * 4 * npad;
+            LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wf, (long long)O, 1LL, Kp, O, npad, 0, imgf);
+        }
+        {   // d-grad: B[k = o][n = k'] = Wd[k'*O + o]
+            const int npad = (Kp + 3) & ~3;
+            const long long n = (long long)((O + 31) / 32) * 4 * npad;
+            LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wd, 1LL, (long long)O, O, Kp, npad, 1, imgd);
+        }
+    }
     return 0;
 }
 static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st) {
@@ -655,6 +672,7 @@ struct ModelPlan {
     SupBufs sup;
     float *dS;                               // [2][nslabS][N*ldS]
     float *Wf[4], *Wd[4], *dWs[4];           // enc gate, enc update, dec gate, dec update
+    uint4 *imgf[4], *imgd[4];                // their pre-split tile images (weight pool / d-grad B operands)
     float *Zenc, *Yenc, *zr_e, *hc_e;
     float *Zdec, *Ydec, *zr_d, *hc_d;
     float *q_rows, *att_rows; int* ind_rows;
@@ -704,6 +722,8 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.Wf[i] = b.take<float>(n);
         P.Wd[i] = b.take<float>(n);
         P.dWs[i] = b.take<float>(n * NSLAB_W);
+        P.imgf[i] = b.take<uint4>(bimg_uint4(sh[i]->G * sh[i]->Cp, Os[i]));
+        P.imgd[i] = b.take<uint4>(bimg_uint4(Os[i], sh[i]->G * sh[i]->Cp));
     }
     const long long R = P.se.R;
     P.Zenc = b.take<float>((size_t)(d->T_in + 1) * P.se.ZT);
@@ -852,14 +872,14 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     Sup u = model_sup(P, N);
     const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
-    for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], st));
+    for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], st, P.imgf[i], P.imgd[i]));
     // ---- encoder (MegaCRN.py:65-83): inputs for all t packed once
     CKI(fill_cols(P.Zenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
     CKI(fill_cols(P.Yenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
     CKI(zero_cols(P.Zenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
     CKI(zero_cols(P.Yenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
     CKI(zero_cols(P.Zenc, se.ZT, se.Cp, 0, H, R, 1, st));   // init_hidden = 0 (:50-51)
-    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b};
+    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     for (int t = 0; t < Ti; ++t)
         CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
                           we, P.Zenc + (t + 1) * se.ZT, se.Cp, st));
@@ -875,7 +895,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, st));
     CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));   // go = 0 (:182)
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));
-    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b};
+    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
         CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
@@ -929,7 +949,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_W * od * Hd * sizeof(float), st));
     // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
     Sup ud = u; ud.defer = P.defer_ds;
-    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b};
+    CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
     for (int t = To - 1; t >= 0; --t) {
         const bool last = t == To - 1;
         const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
@@ -983,7 +1003,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_W,
            (long long)H * D, (long long)H * D, 0);
     // ---- encoder BPTT
-    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b};
+    CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     for (int t = Ti - 1; t >= 0; --t)
         CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                           P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,

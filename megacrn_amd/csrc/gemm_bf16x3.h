@@ -42,6 +42,33 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// Pre-split image of a static B operand (weights): built once per step, consumed by every tile load of every
+// launch that uses it.  element(k, n) = src[k*sk + n*sn]; k >= K or n >= N -> 0.
+__global__ void k_bimg_build(const float* __restrict__ src, long long sk, long long sn, int K, int N, int npad,
+                             int kc_layout, uint4* __restrict__ img) {
+    const int nkt = (K + 31) / 32;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nkt * 4 * npad) return;
+    const int n = (int)(i % npad);
+    const int kg = (int)((i / npad) & 3), kt = (int)(i / npad / 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kt + 8 * kg + j;
+        v[j] = (k < K && n < N) ? src[(long long)k * sk + (long long)n * sn] : 0.f;
+    }
+    uint4 h, l;
+    split8(v, h, l);
+    if (kc_layout) {            // consumer threads are (n, kg) with kg fastest: [kt][n][kg][hi|lo], 32 B per lane
+        img[(((long long)kt * npad + n) * 4 + kg) * 2 + 0] = h;
+        img[(((long long)kt * npad + n) * 4 + kg) * 2 + 1] = l;
+    } else {                    // consumer lanes run along n: [kt][kg][hi|lo][n]
+        img[((long long)(kt * 4 + kg) * 2 + 0) * npad + n] = h;
+        img[((long long)(kt * 4 + kg) * 2 + 1) * npad + n] = l;
+    }
+}
+static inline size_t bimg_uint4(int K, int N) { return (size_t)((K + 31) / 32) * 4 * 2 * ((N + 3) & ~3); }
+
 // ---- operand tile: E rows x 32 k ; thread owns NP (row, k-group-of-8) pairs -------------------
 // Fast path (host-verified, see fast_ok): no divisions, no bounds branches inside the K loop.
 //   rows are clamped to the last valid row (their results are never stored), per-thread pointers
@@ -137,6 +164,38 @@ struct TileX {
             }
         }
     }
+    // pre-split image source: the registers carry the hi (v[0..3]) and lo (v[4..7]) vectors as raw bits
+    __device__ __forceinline__ void load_img(Regs& R, const uint4* __restrict__ img, int kt, int row0, int npad,
+                                             int tid) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            int n = row0 + row[q];
+            if (n >= npad) n = npad - 1;                       // padded columns hold zeros / discarded outputs
+            uint4 h, l;
+            if (KC) {
+                const uint4* b = img + (((long long)kt * npad + n) * 4 + kg[q]) * 2;
+                h = b[0]; l = b[1];
+            } else {
+                const uint4* b = img + ((long long)(kt * 4 + kg[q]) * 2) * npad + n;
+                h = b[0]; l = b[npad];
+            }
+            R.v[q][0] = __uint_as_float(h.x); R.v[q][1] = __uint_as_float(h.y);
+            R.v[q][2] = __uint_as_float(h.z); R.v[q][3] = __uint_as_float(h.w);
+            R.v[q][4] = __uint_as_float(l.x); R.v[q][5] = __uint_as_float(l.y);
+            R.v[q][6] = __uint_as_float(l.z); R.v[q][7] = __uint_as_float(l.w);
+        }
+    }
+    __device__ __forceinline__ void store_img(const Regs& R, uint4* sHi, uint4* sLo, int tid) const {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (tid + 256 * q < E * 4) {
+                sHi[row[q] * 5 + kg[q]] = make_uint4(__float_as_uint(R.v[q][0]), __float_as_uint(R.v[q][1]),
+                                                     __float_as_uint(R.v[q][2]), __float_as_uint(R.v[q][3]));
+                sLo[row[q] * 5 + kg[q]] = make_uint4(__float_as_uint(R.v[q][4]), __float_as_uint(R.v[q][5]),
+                                                     __float_as_uint(R.v[q][6]), __float_as_uint(R.v[q][7]));
+            }
+        }
+    }
     __device__ __forceinline__ void store(const Regs& R, uint4* sHi, uint4* sLo, int tid) const {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -176,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const float* __restrict__ Bb = p.B[batch];
     const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
     const bool afast = (p.vec & 1) != 0, bfast = (p.vec & 2) != 0;
+    const uint4* __restrict__ bimg = p.Bimg;          // non-null: B comes pre-split (static weights)
 #ifdef MCRN_ABLATE
     const int dbg = p.vec >> 8;      // ablation knob (tools/ablate.py, -DMCRN_ABLATE builds only): 1 = no MFMA, 2 = no global loads, 4 = no convert/LDS store, 8 = no barrier
 #else
@@ -213,16 +273,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     do {                                                                                            \
         const bool full_ = kload < kfull;                                                           \
         if (afast && full_) ta.load_fast(RA, p.ak.lo); else ta.load_slow(RA, Ab, kload, kend, p.ak.inner, akhi, p.ak.lo); \
-        if (bfast && full_) tb.load_fast(RB, p.bk.lo); else tb.load_slow(RB, Bb, kload, kend, p.bk.inner, bkhi, p.bk.lo); \
+        if (bimg) tb.load_img(RB, bimg, kload >> 5, n_blk, p.bimg_n, tid);                          \
+        else if (bfast && full_) tb.load_fast(RB, p.bk.lo);                                         \
+        else tb.load_slow(RB, Bb, kload, kend, p.bk.inner, bkhi, p.bk.lo);                          \
         kload += 32;                                                                                \
         if (afast) ta.advance(p.ak.inner, akhi, p.ak.lo);                                           \
-        if (bfast) tb.advance(p.bk.inner, bkhi, p.bk.lo);                                           \
+        if (bfast && !bimg) tb.advance(p.bk.inner, bkhi, p.bk.lo);                                  \
     } while (0)
 #define MCRN_STORE_TILE(RA, RB, STG)                                                                \
     do {                                                                                            \
         uint4* b_ = smem + (STG) * STAGE;                                                           \
         ta.store(RA, b_, b_ + TA::SZ, tid);                                                         \
-        tb.store(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                               \
+        if (bimg) tb.store_img(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                 \
+        else tb.store(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                          \
     } while (0)
     const int l31 = lane & 31, kq = lane >> 5;
 #define MCRN_COMPUTE(STG)                                                                           \

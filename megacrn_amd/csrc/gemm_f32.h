@@ -68,6 +68,10 @@ struct GemmP {
     int H;
     double alg_flops;   // host-side bookkeeping only (algorithmic flops of this launch)
     int vec;            // bf16x3 path: bit0 = A rows float4-loadable, bit1 = B
+    // bf16x3 path: optional pre-split image of the B operand (static weights, gemm_bf16x3.h: k_bimg_build):
+    //   Bimg[((kt*4 + kg)*2 + hl) * bimg_n + n] = 8 bf16 (hi | lo) of B[k = 32 kt + 8 kg + 0..7][n]
+    const uint4* Bimg;
+    int bimg_n;
 };
 
 __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {
