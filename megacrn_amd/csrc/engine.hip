@@ -275,7 +275,7 @@ static GemmP gp() {
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
     if (use_prop_small(u, s) && aligned16(Z) && s.K == 3) {   // both hops, one launch
         Prop2P q;
-        q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         const double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
         const double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), ex, alg);
@@ -336,7 +336,9 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
-                         const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr) {
+                         const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
+                         float* dT = nullptr, bool* used_dT = nullptr) {
+    if (used_dT) *used_dT = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
     {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
@@ -349,12 +351,13 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
-    const bool fused_bwd = small && s.K == 3;
+    const bool fused_bwd = small && s.K == 3 && dT != nullptr;
     if (fused_bwd) {
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
-        q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        if (used_dT) *used_dT = true;
         const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
     } else if (s.K == 3 && small) {
@@ -511,13 +514,15 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
 
 static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float* Y, const float* zr,
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
-                         float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st) {
+                         float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
+                         float* dTg = nullptr) {
     const long long RH = s.R * s.H;
+    bool xu = false, xg = false;
     LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u));
-    LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g));
-    LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dP, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu));
+    LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg));
+    LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     return 0;
 }
 
@@ -676,7 +681,7 @@ struct ModelPlan {
     float *Zenc, *Yenc, *zr_e, *hc_e;
     float *Zdec, *Ydec, *zr_d, *hc_d;
     float *q_rows, *att_rows; int* ind_rows;
-    float *dP, *dQ;
+    float *dP, *dQ, *dTu, *dTg;
     float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
     float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
     bool defer_ds;
@@ -740,6 +745,11 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     size_t zmax = (size_t)(P.se.ZT > P.sd.ZT ? P.se.ZT : P.sd.ZT);
     P.dP = b.take<float>(zmax);
     P.dQ = b.take<float>(zmax);
+    {
+        size_t pmax = (size_t)(P.se.PS > P.sd.PS ? P.se.PS : P.sd.PS);
+        P.dTu = b.take<float>(pmax);
+        P.dTg = b.take<float>(pmax);
+    }
     P.dPall_e = P.dSdef = nullptr;
     P.dPall_d = P.defer_ds ? b.take<float>((size_t)d->T_out * 2 * P.sd.ZT) : nullptr;
     P.dU_e = b.take<float>((size_t)d->T_in * R * H);
@@ -960,7 +970,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                           wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd,
                           P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dP,
-                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ, P.dacc_d, P.dxin_d, st));
+                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ, P.dacc_d, P.dxin_d, st, P.dTu, P.dTg));
     }
     // Decoder weight/bias/projection gradients depend only on the finished decoder BPTT: run them on the
     // helper stream so they overlap the memory-head and encoder backward below (joined before the adjacency
@@ -1007,7 +1017,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     for (int t = Ti - 1; t >= 0; --t)
         CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                           P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
-                          P.dP, P.dQ, P.dacc_e, P.dxin_e, st));
+                          P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg));
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
     CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st));
     CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st));
@@ -1036,7 +1046,7 @@ struct CellPlan {
     float *St1, *St2, *dS;
     uint4* frag[4];
     int nslabS;
-    float *dP, *dQ, *dU, *dG, *dacc, *dxin, *part;
+    float *dP, *dQ, *dTu, *dTg, *dU, *dG, *dacc, *dxin, *part;
     size_t total;
 };
 static void plan_cell(int B, int N, int din, int H, int K, char* base, CellPlan& P) {
@@ -1056,6 +1066,7 @@ static void plan_cell(int B, int N, int din, int H, int K, char* base, CellPlan&
     P.nslabS = nslab_S(N);
     P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
     P.dP = b.take<float>((size_t)s.ZT); P.dQ = b.take<float>((size_t)s.ZT);
+    P.dTu = b.take<float>((size_t)s.PS); P.dTg = b.take<float>((size_t)s.PS);
     P.dU = b.take<float>((size_t)s.R * H); P.dG = b.take<float>((size_t)s.R * 2 * H);
     P.dacc = b.take<float>((size_t)s.R * H); P.dxin = b.take<float>((size_t)s.R * (din > 0 ? din : 1));
     P.part = b.take<float>(colsum_part_floats(s.R, 2 * H) + 1024);
@@ -1372,7 +1383,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CK(hipMemsetAsync(P.dWs[1], 0, (size_t)s.G * s.Cp * H * NSLAB_W * sizeof(float), st));
     CKI(bnc_to_rows(P.dacc, H, 0, H, dhn, B, N, st));
     CellW w{P.Wf[0], P.Wd[0], nullptr, P.Wf[1], P.Wd[1], nullptr};
-    CKI(cell_bwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.dacc, P.dU, P.dG, P.dP, P.dQ, P.dacc, P.dxin, st));
+    CKI(cell_bwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.dacc, P.dU, P.dG, P.dP, P.dQ, P.dacc, P.dxin, st, P.dTu, P.dTg));
     CKI(side_join(st));
     CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dG, 2 * H, P.dWs[0], st));
     CKI(agcn_wgrad(s, P.Y, s.ZT, 1, P.dU, H, P.dWs[1], st));

@@ -449,29 +449,37 @@ __global__ void k_cell_bwd_a(const float* __restrict__ dhn, const float* __restr
     dacc[i] = g * rr;
 }
 // B: dzh = dY0[state part] ; dG[:, :H] = dzh*h*z*(1-z) ; dacc += dzh*z
-__global__ void k_cell_bwd_b(const float* __restrict__ dy0, long long ldy, const float* __restrict__ z0,
-                             long long ldz, const float* __restrict__ zr, int H, long long R,
-                             float* __restrict__ dG, float* __restrict__ dacc) {
+__global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ldy,
+                             const float* __restrict__ z0, long long ldz, const float* __restrict__ zr, int H,
+                             long long R, float* __restrict__ dG, float* __restrict__ dacc) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * H) return;
     int c = (int)(i % H);
     long long r = i / H;
     float dzh = dy0[r * ldy + c];
+    if (dy0x) dzh += dy0x[r * ldy + c];          // second support's S^T contribution (prop2_bwd_kernel)
     float h = z0[r * ldz + c];
     float z = zr[r * 2 * H + c];
     dG[r * 2 * H + c] = dzh * h * z * (1.f - z);
     dacc[i] += dzh * z;
 }
 // C: dh_prev = dacc + dZ0[state] ; dxin = dY0[input] + dZ0[input]
-__global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dy0, long long ld,
+__global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dz0x,
+                             const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ld,
                              int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int C = H + d;
     if (i >= R * C) return;
     int c = (int)(i % C);
     long long r = i / C;
-    if (c < H) dacc[r * H + c] += dz0[r * ld + c];
-    else dxin[r * d + (c - H)] = dz0[r * ld + c] + dy0[r * ld + c];
+    float a = dz0[r * ld + c];
+    if (dz0x) a += dz0x[r * ld + c];
+    if (c < H) dacc[r * H + c] += a;
+    else {
+        float b = dy0[r * ld + c];
+        if (dy0x) b += dy0x[r * ld + c];
+        dxin[r * d + (c - H)] = a + b;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

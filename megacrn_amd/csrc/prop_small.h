@@ -249,6 +249,7 @@ struct PropBlock {
 struct Prop2P {
     const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
     float* base;                // plane set (Z for forward, dP for backward)
+    float* extra;               // backward: support 1 stores S_2^T d1t_2 here (consumers add it to dP[0])
     long long PS, ld;
     int N, ncols;
 };
@@ -315,63 +316,61 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     }
 }
 
-// backward, one workgroup per 32*CT columns, both supports:
+// backward, one workgroup per (32*CT columns, support s = blockIdx.y):
 //   d1t_s = dP[1+2s] + S_s^T dP[2+2s]   (written back to dP[1+2s])
-//   dP[0] += S_1^T d1t_1 + S_2^T d1t_2   (read-modify-write by the same lane for both supports: fixed order)
+//   s = 0:  dP[0] += S_1^T d1t_1        (read-modify-write)
+//   s = 1:  extra  = S_2^T d1t_2        (plain store; the consumers of dP[0] add it)
+// Each element has exactly one writer, so the result is deterministic while both supports run on different CUs.
 template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     using PB = PropBlock<NF, CT>;
     constexpr int KS = 2 * NF;
     __shared__ uint4 img[PB::IMG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int colbase = blockIdx.x * 32 * CT;
+    const int s = blockIdx.y, colbase = blockIdx.x * 32 * CT;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
-    float* __restrict__ D0 = p.base;
-#pragma unroll 1
-    for (int s = 0; s < 2; ++s) {
-        float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
-        const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
-        int opq = 0;                                   // opaque zero: keeps the element offsets below from
-        asm volatile("" : "+s"(opq));                  // being hoisted out of the support loop (64 VGPRs)
-        const int ldi = (int)p.ld + opq;
-        uint4 ah[KS], al[KS];
-        PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
-        if (s > 0) __syncthreads();                    // previous image fully consumed
-        PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
-        __syncthreads();
-        f32x16 acc[CT];
-        PB::mma(img, ah, al, acc, lane);
+    const int ldi = (int)p.ld;
+    float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
+    const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
+    uint4 ah[KS], al[KS];
+    PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
+    __syncthreads();
+    f32x16 acc[CT];
+    PB::mma(img, ah, al, acc, lane);
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int col = colbase + 32 * t + cperm;
+    for (int t = 0; t < CT; ++t) {
+        const int col = colbase + 32 * t + cperm;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-                if (r < p.N && col < p.ncols) {
-                    const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
-                    const float d = acc[t][v] + D1[off];
-                    acc[t][v] = d;
-                    D1[off] = d;
-                } else {
-                    acc[t][v] = 0.f;
-                }
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N && col < p.ncols) {
+                const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
+                const float d = acc[t][v] + D1[off];
+                acc[t][v] = d;
+                D1[off] = d;
+            } else {
+                acc[t][v] = 0.f;
             }
         }
-        __syncthreads();
-        PB::to_img(img, acc, w, lane);
-        __syncthreads();
-        PB::mma(img, ah, al, acc, lane);
+    }
+    __syncthreads();
+    PB::to_img(img, acc, w, lane);
+    __syncthreads();
+    PB::mma(img, ah, al, acc, lane);
+    float* __restrict__ D0 = p.base;
+    float* __restrict__ EX = p.extra;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int col = colbase + 32 * t + cperm;
+    for (int t = 0; t < CT; ++t) {
+        const int col = colbase + 32 * t + cperm;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-                if (r < p.N && col < p.ncols) {
-                    const int off = r * ldi + col;
-                    D0[off] = D0[off] + acc[t][v];
-                }
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N && col < p.ncols) {
+                const int off = r * ldi + col;
+                if (s == 0) D0[off] = D0[off] + acc[t][v];
+                else EX[off] = acc[t][v];
             }
         }
     }
@@ -409,11 +408,11 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
-    if (pick_ct(p.ncols, 1) == 1) {
-        dim3 grid((p.ncols + 31) / 32, 1);
+    if (pick_ct(p.ncols, 2) == 1) {
+        dim3 grid((p.ncols + 31) / 32, 2);
         MCRN_NF_SWITCH(prop2_bwd_kernel, 1, grid, p)
     } else {
-        dim3 grid((p.ncols + 63) / 64, 1);
+        dim3 grid((p.ncols + 63) / 64, 2);
         MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p)
     }
     return hipGetLastError();
