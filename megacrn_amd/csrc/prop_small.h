@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     constexpr int KS = 2 * NF;
     __shared__ uint4 img[PB::IMG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = blockIdx.y, colbase = blockIdx.x * 32 * CT;
+    const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
     const float* __restrict__ X0 = p.base;
@@ -270,8 +270,15 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
     const int ldi = (int)p.ld;
 
+    // S stays in registers while the workgroup walks its balanced range of column units: the grid is capped
+    // so that all workgroups are resident at once (no second round when #units is just above #CUs)
     uint4 ah[KS], al[KS];
     PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    for (int unit = u0; unit < u1; ++unit) {
+    const int colbase = unit * 32 * CT;
+    if (unit > u0) __syncthreads();                    // previous unit's hop-2 image fully consumed
     // x0 in accumulator layout for the final "2 S x1 - x0": requested now, consumed after both hops, so the
     // kernel exposes ONE memory round-trip instead of two (the lines are the ones being staged anyway)
     f32x16 x0c[CT];
@@ -314,6 +321,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
             }
         }
     }
+    }   // unit loop
 }
 
 // backward, one workgroup per (32*CT columns, support s = blockIdx.y):
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     constexpr int KS = 2 * NF;
     __shared__ uint4 img[PB::IMG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = blockIdx.y, colbase = blockIdx.x * 32 * CT;
+    const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
     const int ldi = (int)p.ld;
@@ -335,6 +343,11 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
     uint4 ah[KS], al[KS];
     PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    for (int unit = u0; unit < u1; ++unit) {
+    const int colbase = unit * 32 * CT;
+    if (unit > u0) __syncthreads();
     PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
     __syncthreads();
     f32x16 acc[CT];
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
             }
         }
     }
+    }   // unit loop
 }
 
 #define MCRN_NF_SWITCH(KERN, CT_, GRID, P)                                                   \
@@ -396,11 +410,9 @@ static inline int pick_ct(int ncols, int ny) {
 static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
-    if (pick_ct(p.ncols, 2) == 1) {
-        dim3 grid((p.ncols + 31) / 32, 2);
-        MCRN_NF_SWITCH(prop2_fwd_kernel, 1, grid, p)
-    } else {
-        dim3 grid((p.ncols + 63) / 64, 2);
+    {
+        const int nunits = (p.ncols + 63) / 64;
+        dim3 grid(nunits < 128 ? nunits : 128, 2);        // 2 supports x <= 128 = all workgroups resident on 256 CUs
         MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p)
     }
     return hipGetLastError();
@@ -408,11 +420,9 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
-    if (pick_ct(p.ncols, 2) == 1) {
-        dim3 grid((p.ncols + 31) / 32, 2);
-        MCRN_NF_SWITCH(prop2_bwd_kernel, 1, grid, p)
-    } else {
-        dim3 grid((p.ncols + 63) / 64, 2);
+    {
+        const int nunits = (p.ncols + 63) / 64;
+        dim3 grid(nunits < 128 ? nunits : 128, 2);
         MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p)
     }
     return hipGetLastError();
