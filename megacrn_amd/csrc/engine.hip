@@ -243,6 +243,9 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     const float* St[2];
     const uint4* Sf[2];     // fragment-ordered bf16 hi/lo split of S (prop_small.h), or nullptr
     const uint4* Stf[2];    // same for S^T
+    const uint4* Simg[2];   // tile-ordered pre-split images of S / S^T for the tiled GEMM (N > 256), or nullptr
+    const uint4* Stimg[2];
+    int simg_n;
     long long ldS;
     float* dS;      // [2][nslab][N*ldS]
     int nslab;
@@ -300,6 +303,8 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
     p.bk = plain(s.ld);  p.bn = plain(1);
     p.cm = plain(s.ld);  p.cn = plain(1);
     p.nbatch = 2;
+    const bool simg = g_precision == MCRN_BF16X3 && u.Simg[0] != nullptr;
+    if (simg) { p.Aimg[0] = u.Simg[0]; p.Aimg[1] = u.Simg[1]; p.aimg_n = u.simg_n; }
     for (int b = 0; b < 2; ++b) {
         p.A[b] = u.S[b];
         p.B[b] = Z;
@@ -376,6 +381,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.bk = plain(s.ld); p.bn = plain(1);
         p.cm = plain(s.ld); p.cn = plain(1);
         p.nbatch = 2; p.beta = 1.f;
+        if (g_precision == MCRN_BF16X3 && u.Stimg[0]) { p.Aimg[0] = u.Stimg[0]; p.Aimg[1] = u.Stimg[1]; p.aimg_n = u.simg_n; }
         for (int b = 0; b < 2; ++b) {
             p.A[b] = u.St[b];
             p.B[b] = dP + (2 + 2 * b) * s.PS;
@@ -447,7 +453,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         q.X[0][0] = dP + s.PS; q.X[0][1] = dP + (long long)(1 + (s.K - 1)) * s.PS;
         q.C[0] = dP; q.Cin[0] = dP;
         CKI(prop_small(q, 1, ROLE_PROPT, 0, st));
-    } else if ((s.N & 3) == 0) {   // dx0 = dP[0] + [S1^T | S2^T] [d1t_a ; d1t_b] : one K-concatenated GEMM
+    } else if ((s.N & 3) == 0 && !(g_precision == MCRN_BF16X3 && u.Stimg[0])) {   // one K-concatenated GEMM
         GemmP p = gp();
         p.M = s.N; p.N = (int)s.ld; p.K = 2 * s.N;
         p.A[0] = u.St[0]; p.am = plain(u.ldS);
@@ -462,6 +468,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             GemmP p = gp();
             p.M = s.N; p.N = (int)s.ld; p.K = s.N;
             p.A[0] = u.St[b]; p.am = plain(u.ldS); p.ak = plain(1);
+            if (g_precision == MCRN_BF16X3 && u.Stimg[b]) { p.Aimg[0] = u.Stimg[b]; p.aimg_n = u.simg_n; }
             p.B[0] = dP + (long long)(1 + b * (s.K - 1)) * s.PS; p.bk = plain(s.ld); p.bn = plain(1);
             p.C[0] = dP; p.Cin[0] = dP; p.cm = plain(s.ld); p.cn = plain(1);
             p.beta = 1.f;
@@ -527,7 +534,7 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
 }
 
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
-struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; uint4* frag[4]; };
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
 static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
     o.ldS = ldS;
@@ -538,6 +545,8 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     o.dLa = b.take<float>(nn); o.dLb = b.take<float>(nn); o.dLs = b.take<float>(nn);
     o.dE1 = b.take<float>(nd); o.dE2 = b.take<float>(nd);
     for (int i = 0; i < 4; ++i) o.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
+    o.simg_n = (N + 3) & ~3;
+    for (int i = 0; i < 4; ++i) o.simg[i] = N > 256 ? b.take<uint4>(bimg_uint4(N, N)) : nullptr;
 }
 static int transpose(float* dst, long long ldd, const float* src, long long lds_, const float* add,
                      long long lda, int N, hipStream_t st) {
@@ -579,6 +588,13 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
         CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
         CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
         CKI(build_frags(g1, g2, ldg, N, o.frag, st));
+        if (o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
+            const float* src[4] = {g1, g2, o.St1, o.St2};
+            const long long lds_[4] = {ldg, ldg, o.ldS, o.ldS};
+            const long long n = (long long)((N + 31) / 32) * 4 * o.simg_n;
+            for (int i = 0; i < 4; ++i)
+                LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, src[i], 1LL, lds_[i], N, N, o.simg_n, 1, o.simg[i]);
+        }
     }
     return 0;
 }
@@ -779,6 +795,8 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.S[0] = P.sup.g1; u.S[1] = P.sup.g2;
     u.St[0] = P.sup.St1; u.St[1] = P.sup.St2;
     u.Sf[0] = P.sup.frag[0]; u.Sf[1] = P.sup.frag[1]; u.Stf[0] = P.sup.frag[2]; u.Stf[1] = P.sup.frag[3];
+    u.Simg[0] = P.sup.simg[0]; u.Simg[1] = P.sup.simg[1]; u.Stimg[0] = P.sup.simg[2]; u.Stimg[1] = P.sup.simg[3];
+    u.simg_n = P.sup.simg_n;
     u.ldS = P.ldS;
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
     u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
@@ -1297,7 +1315,7 @@ int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, co
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(wprep(W, P.Wf, P.Wd, s, O, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
     CKI(bnc_to_rows(P.Z, s.Cp, 0, C, x, B, N, st));
@@ -1317,7 +1335,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
@@ -1351,7 +1369,7 @@ int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, 
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(wprep(gate_w, P.Wf[0], P.Wd[0], s, 2 * H, st));
     CKI(wprep(update_w, P.Wf[1], P.Wd[1], s, H, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
@@ -1375,7 +1393,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));

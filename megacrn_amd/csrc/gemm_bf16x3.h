@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const long long akhi = p.ak_hi[batch], bkhi = p.bk_hi[batch];
     const bool afast = (p.vec & 1) != 0, bfast = (p.vec & 2) != 0;
     const uint4* __restrict__ bimg = p.Bimg;          // non-null: B comes pre-split (static weights)
+    const uint4* __restrict__ aimg = p.Aimg[batch];   // non-null: A comes pre-split (static adjacency)
 #ifdef MCRN_ABLATE
     const int dbg = p.vec >> 8;      // ablation knob (tools/ablate.py, -DMCRN_ABLATE builds only): 1 = no MFMA, 2 = no global loads, 4 = no convert/LDS store, 8 = no barrier
 #else
@@ -272,18 +273,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 #define MCRN_LOAD_TILE(RA, RB)                                                                      \
     do {                                                                                            \
         const bool full_ = kload < kfull;                                                           \
-        if (afast && full_) ta.load_fast(RA, p.ak.lo); else ta.load_slow(RA, Ab, kload, kend, p.ak.inner, akhi, p.ak.lo); \
+        if (aimg) ta.load_img(RA, aimg, kload >> 5, m_blk, p.aimg_n, tid);                          \
+        else if (afast && full_) ta.load_fast(RA, p.ak.lo);                                         \
+        else ta.load_slow(RA, Ab, kload, kend, p.ak.inner, akhi, p.ak.lo);                          \
         if (bimg) tb.load_img(RB, bimg, kload >> 5, n_blk, p.bimg_n, tid);                          \
         else if (bfast && full_) tb.load_fast(RB, p.bk.lo);                                         \
         else tb.load_slow(RB, Bb, kload, kend, p.bk.inner, bkhi, p.bk.lo);                          \
         kload += 32;                                                                                \
-        if (afast) ta.advance(p.ak.inner, akhi, p.ak.lo);                                           \
+        if (afast && !aimg) ta.advance(p.ak.inner, akhi, p.ak.lo);                                  \
         if (bfast && !bimg) tb.advance(p.bk.inner, bkhi, p.bk.lo);                                  \
     } while (0)
 #define MCRN_STORE_TILE(RA, RB, STG)                                                                \
     do {                                                                                            \
         uint4* b_ = smem + (STG) * STAGE;                                                           \
-        ta.store(RA, b_, b_ + TA::SZ, tid);                                                         \
+        if (aimg) ta.store_img(RA, b_, b_ + TA::SZ, tid); else ta.store(RA, b_, b_ + TA::SZ, tid);  \
         if (bimg) tb.store_img(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                 \
         else tb.store(RB, b_ + 2 * TA::SZ, b_ + 2 * TA::SZ + TB::SZ, tid);                          \
     } while (0)

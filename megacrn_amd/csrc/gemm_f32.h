@@ -72,6 +72,9 @@ struct GemmP {
     //   Bimg[((kt*4 + kg)*2 + hl) * bimg_n + n] = 8 bf16 (hi | lo) of B[k = 32 kt + 8 kg + 0..7][n]
     const uint4* Bimg;
     int bimg_n;
+    // same for a static A operand (the adjacency of the tiled propagation at N > 256), per batch, KC layout
+    const uint4* Aimg[2];
+    int aimg_n;
 };
 
 __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {

@@ -323,3 +323,33 @@ def test_train_loop_counterpart_runs_and_learns(amd, tmp_path):
     assert saved, "best-val checkpoint missing"
     sd = torch.load(saved[0])
     assert list(sd.keys())[:4] == ["memory.Memory", "memory.Wq", "memory.We1", "memory.We2"]
+
+
+@pytest.mark.parametrize("N,cheb_k", [(300, 3), (261, 2)])
+def test_model_large_graph_vs_oracle(amd, N, cheb_k):
+    """N > 256 takes the tiled-GEMM propagation path (pre-split adjacency images, split-K adjacency gradient)
+    instead of the adjacency-stationary kernels: forward and every parameter gradient vs the float64 oracle."""
+    B, T, H, M, D = 3, 3, 12, 6, 8
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=11)
+    rng = np.random.default_rng(4)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    teacher = [True, False, True]
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000)
+    model = build(amd, P, m).train()
+    model._teacher_flags = lambda labels, bs: teacher
+    outs = model(dev(x), dev(ycov), dev(y), 0)
+    wts = [rng.standard_normal(o.shape) for o in outs[:3]]
+    sum((o * dev(w)).sum() for o, w in zip(outs[:3], wts)).backward()
+    torch.cuda.synchronize()
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    o64, cache = O.model_fwd(P64, x.astype(np.float64), ycov.astype(np.float64), y.astype(np.float64), teacher, cheb_k=cheb_k)
+    for a, b in zip(outs[:3], o64[:3]):
+        assert relerr(a.detach().cpu().numpy(), b) < TOL
+    G, _ = O.model_bwd(wts[0], cache, d_hatt=wts[1], d_query=wts[2])
+    worst = {k: relerr(p.grad.cpu().numpy(), G[k]) for k, p in model.named_parameters()}
+    assert max(worst.values()) < TOL, worst
