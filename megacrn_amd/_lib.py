@@ -13,7 +13,8 @@ import torch  # noqa: F401  MUST precede loading the .so: PyTorch bundles its ow
 #                     with "no ROCm-capable device").  With torch loaded, the soname resolves to the same runtime.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmegacrn_hip.so")
+# MEGACRN_LIB: measurement-only build variants (csrc/Makefile `timeline` / `ablate`); default is the shipped library
+LIB_PATH = os.environ.get("MEGACRN_LIB") or os.path.join(_HERE, "libmegacrn_hip.so")
 
 EXPORTS = [
     "mcrn_last_error", "mcrn_version", "mcrn_last_launch_count",

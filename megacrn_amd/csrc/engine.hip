@@ -27,7 +27,7 @@ namespace mcrn {
 
 GemmStats g_gemm_stats = {0, 0.0};
 int g_force_cfg = -1;
-int g_debug = 0;
+int g_debug = getenv("MCRN_DEBUG") ? atoi(getenv("MCRN_DEBUG")) : 0;   // tuning A/B bits, 0 in production
 static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch
 static char g_err[512] = "";
 static int g_launches = 0;
@@ -1157,6 +1157,14 @@ int mcrn_last_launch_count(void) { return g_launches; }
 
 int mcrn_set_gemm_cfg(int cfg) { g_force_cfg = cfg; return 0; }
 int mcrn_set_debug(int bits) { g_debug = bits; return 0; }
+#ifdef MCRN_TIMELINE
+// measurement-only builds: copy out the in-kernel phase stamps (prop_small.h)
+int mcrn_debug_timeline(void* host_out, size_t bytes) {
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tl), bytes < sizeof(g_tl) ? bytes : sizeof(g_tl)));
+    return 0;
+}
+#endif
 
 int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream) {
     CKI(check_dims(d));

@@ -223,7 +223,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    int tile_m, tile_n;
+    if (p.vec & (1 << 12)) {                     // debug bit 16: plain column-major tile order
+        tile_m = blockIdx.x % tiles_m; tile_n = blockIdx.x / tiles_m;
+    } else {
+        // XCD-aware order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so give XCD x
+        // the contiguous logical range [x*per, (x+1)*per) and walk that range in GM-row groups: the blocks
+        // resident on one XCD then cover a compact patch of C and share A row-panels / B column-panels in L2.
+        const int nblk = gridDim.x, per = nblk >> 3, full = per << 3;
+        const int bid = blockIdx.x;
+        const int L = bid < full ? (bid & 7) * per + (bid >> 3) : bid;
+        constexpr int GM = 4;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int width = GM * tiles_n;
+        const int grp = L / width, first_m = grp * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int r = L - grp * width;
+        tile_m = first_m + r % gsz; tile_n = r / gsz;
+    }
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const int z = blockIdx.z;
     const int batch = z / p.nsplit, split = z - batch * p.nsplit;
@@ -364,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 }
 
 // ---- host launcher ------------------------------------------------------------------------
+#ifndef MCRN_PROBE   // compile-only probes (probe_prop.hip) skip the launchers: they instantiate every tile configuration
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one_x3(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
@@ -430,5 +448,7 @@ static inline hipError_t launch_gemm_x3(GemmP p, bool akc, bool bkc, int max_spl
     if (fast_ok(bkc, p.B, p.nbatch, p.bn, p.bk, p.bk_hi)) p.vec |= 2;
     return launch_role_x3(p, akc, bkc, role, cfg, st);
 }
+
+#endif  // MCRN_PROBE
 
 }  // namespace mcrn

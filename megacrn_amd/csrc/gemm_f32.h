@@ -289,6 +289,7 @@ extern GemmStats g_gemm_stats;
 extern int g_force_cfg;   // >= 0: force this tile configuration (tuning sweeps)
 extern int g_debug;       // ablation bits for the bf16x3 kernel (0 in production)
 
+#ifndef MCRN_PROBE
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);
@@ -368,5 +369,7 @@ static inline hipError_t launch_gemm_f32(GemmP p, bool akc, bool bkc, int max_sp
     const int cfg = choose_cfg(p, max_split, 16);
     return launch_f32(p, akc, bkc, cfg, st);
 }
+
+#endif  // MCRN_PROBE
 
 }  // namespace mcrn

@@ -149,20 +149,24 @@ template <int NF, int CT>      // CT = 32-column tiles per workgroup (1 or 2)
 struct PropBlock {
     static constexpr int KS = 2 * NF;
     static constexpr int IMG = CT * KS * 2 * 64;     // uint4
-    // stage 32*CT columns of a plane into the B image: thread = (4-column group, 8-k group)
-    static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, long long ld, int N,
+    // stage 32*CT columns of a plane into the B image: thread = (4-column group, 8-k group).
+    // The 8 loads are UNCONDITIONAL from clamped in-range addresses and zeroed afterwards: a load under a
+    // divergent branch gets its own basic block and (measured with the in-kernel timeline) one full memory
+    // round trip each.  Offsets are 32-bit: base lane offset + scalar multiples of the row stride.
+    static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, int ld, int nlast /* N-1 */,
                                                  int ncols, int colbase, int tid) {
         const int cg = tid % (8 * CT), kg = tid / (8 * CT);
         if (kg >= 4 * NF) return;                     // CT == 1: half of the threads have no item
         const int col = colbase + 4 * cg;
-        const bool cv = col < ncols;
+        const bool cv = col < ncols;                  // ncols % 4 == 0: a float4 is all-in or all-out
+        const int colc = cv ? col : 0;
         float v[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = 8 * kg + i;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cv && k < N) t = *reinterpret_cast<const float4*>(X + (long long)k * ld + col);
-            v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+            const float4 t = *reinterpret_cast<const float4*>(X + (unsigned)(min(k, nlast) * ld + colc));
+            const bool ok = k <= nlast;
+            v[i][0] = ok ? t.x : 0.f; v[i][1] = ok ? t.y : 0.f; v[i][2] = ok ? t.z : 0.f; v[i][3] = ok ? t.w : 0.f;
         }
         const int ct = cg >> 3, ks = kg >> 1, kqq = kg & 1;
 #pragma unroll
@@ -170,6 +174,7 @@ struct PropBlock {
             const float col8[8] = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
             uint4 h, l;
             split8(col8, h, l);
+            if (!cv) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
             const int slot = c * 8 + (cg & 7) + 32 * kqq;
             img[((ct * KS + ks) * 2 + 0) * 64 + slot] = h;
             img[((ct * KS + ks) * 2 + 1) * 64 + slot] = l;
@@ -246,6 +251,20 @@ struct PropBlock {
     }
 };
 
+// Measurement-only build (-DMCRN_TIMELINE=1|2, `make timeline [FENCE=2]`): thread 0 of every workgroup stamps the
+// 100 MHz wall clock at phase boundaries; =2 also drains the memory counters first so that a phase's
+// time includes the latency of what it issued.  kind 0 = prop2_fwd, 1 = prop2_bwd, 2 = ds_small.
+#ifdef MCRN_TIMELINE
+__device__ unsigned long long g_tl[3][512][12];
+#define MCRN_TL(kind, i)                                                                            \
+    do {                                                                                            \
+        if (MCRN_TIMELINE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
+        if (threadIdx.x == 0) g_tl[kind][(blockIdx.y * gridDim.x + blockIdx.x) & 511][i] = wall_clock64(); \
+    } while (0)
+#else
+#define MCRN_TL(kind, i)
+#endif
+
 struct Prop2P {
     const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
     float* base;                // plane set (Z for forward, dP for backward)
@@ -253,6 +272,15 @@ struct Prop2P {
     long long PS, ld;
     int N, ncols;
 };
+
+// Element addressing shared by the fused kernels.  Lane (l31, kq) of wave w owns, per column tile t and
+// accumulator register v, the element (row 32w + 4kq + (v&3) + 8(v>>2), column colbase + 32t + cperm).
+// Offsets are 32-bit (< 2^31: one plane of an N <= 256 graph) = lane base + a SCALAR multiple of the row
+// stride; the stride is re-read through an opaque move every unit so the 32 row offsets are not hoisted
+// out of the unit loop into 64 live VGPRs (that spilled, and every reload drained vmcnt: 12 us per unit).
+#define MCRN_ROW_OF(v) (((v) & 3) + 8 * ((v) >> 2))
+// re-read before every load / store phase: offsets are recomputed (16 adds) instead of kept live across the MFMA phases
+#define MCRN_FRESH(x) asm volatile("" : "+s"(x))
 
 // forward, one workgroup per (32*CT columns, support s = blockIdx.y):
 //   plane[1+2s] = S_s plane[0] ;  plane[2+2s] = 2 S_s plane[1+2s] - plane[0]      (model/MegaCRN.py:20-25)
@@ -268,60 +296,84 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     const float* __restrict__ X0 = p.base;
     float* __restrict__ X1 = p.base + (long long)(1 + 2 * s) * p.PS;
     float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
-    const int ldi = (int)p.ld;
+    const int row0 = 32 * w + 4 * kq;
+    const bool rows_in = 32 * w + 32 <= p.N;           // wave-uniform: every row of this wave exists
 
     // S stays in registers while the workgroup walks its balanced range of column units: the grid is capped
     // so that all workgroups are resident at once (no second round when #units is just above #CUs)
     uint4 ah[KS], al[KS];
+    MCRN_TL(0, 0);
     PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    MCRN_TL(0, 1);
     const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
     for (int unit = u0; unit < u1; ++unit) {
-    const int colbase = unit * 32 * CT;
-    if (unit > u0) __syncthreads();                    // previous unit's hop-2 image fully consumed
-    // x0 in accumulator layout for the final "2 S x1 - x0": requested now, consumed after both hops, so the
-    // kernel exposes ONE memory round-trip instead of two (the lines are the ones being staged anyway)
-    f32x16 x0c[CT];
+        const int colbase = unit * 32 * CT;
+        int ld = (int)p.ld;
+        asm volatile("" : "+s"(ld));                   // see MCRN_ROW_OF
+        if (unit > u0) __syncthreads();                // previous unit's hop-2 image fully consumed
+        MCRN_TL(0, 2);
+        int nlast = p.N - 1;
+        MCRN_FRESH(ld); MCRN_FRESH(nlast);              // nothing the loads need is hoisted out of the unit loop (and spilled)
+        PB::stage(img, X0, ld, nlast, p.ncols, colbase, tid);
+        MCRN_TL(0, 3);
+        // x0 in accumulator layout for the final "2 S x1 - x0": requested here (the staging registers are free
+        // again and the lines were just staged, so these are cache hits), consumed after both hops.
+        // Clamped addresses, no predicate: out-of-range elements are never stored.
+        MCRN_FRESH(ld);
+        f32x16 x0c[CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = colbase + 32 * t + cperm;
+        for (int t = 0; t < CT; ++t) {
+            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+            if (rows_in) {
+                const unsigned o = (unsigned)(row0 * ld + col);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            x0c[t][v] = (r < p.N && col < p.ncols) ? X0[r * ldi + col] : 0.f;
-        }
-    }
-    PB::stage(img, X0, p.ld, p.N, p.ncols, colbase, tid);
-    __syncthreads();
-    f32x16 acc[CT];
-    PB::mma(img, ah, al, acc, lane);
-    // X1 out (fp32) + next image
+                for (int v = 0; v < 16; ++v) x0c[t][v] = X0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
+            } else {
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = colbase + 32 * t + cperm;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N && col < p.ncols) X1[r * ldi + col] = acc[t][v];
-        }
-    }
-    __syncthreads();                                   // every wave finished reading the hop-1 image
-    PB::to_img(img, acc, w, lane);
-    __syncthreads();
-    PB::mma(img, ah, al, acc, lane);
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = colbase + 32 * t + cperm;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N && col < p.ncols) {
-                const int off = r * ldi + col;
-                X2[off] = 2.f * acc[t][v] - x0c[t][v];
+                for (int v = 0; v < 16; ++v) x0c[t][v] = X0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
             }
         }
-    }
+        __syncthreads();
+        MCRN_TL(0, 4);
+        f32x16 acc[CT];
+        PB::mma(img, ah, al, acc, lane);
+        // X1 out (fp32) + next image
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            if (col < p.ncols) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = acc[t][v];
+            }
+        }
+        MCRN_TL(0, 5);
+        __syncthreads();                               // every wave finished reading the hop-1 image
+        MCRN_TL(0, 6);
+        PB::to_img(img, acc, w, lane);
+        __syncthreads();
+        MCRN_TL(0, 7);
+        PB::mma(img, ah, al, acc, lane);
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            if (col < p.ncols) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X2[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = 2.f * acc[t][v] - x0c[t][v];
+            }
+        }
+        MCRN_TL(0, 8);
     }   // unit loop
+#ifdef MCRN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) g_tl[0][(blockIdx.y * gridDim.x + blockIdx.x) & 511][9] = wall_clock64();
+#endif
 }
 
 // backward, one workgroup per (32*CT columns, support s = blockIdx.y):
@@ -329,6 +381,8 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
 //   s = 0:  dP[0] += S_1^T d1t_1        (read-modify-write)
 //   s = 1:  extra  = S_2^T d1t_2        (plain store; the consumers of dP[0] add it)
 // Each element has exactly one writer, so the result is deterministic while both supports run on different CUs.
+// The addends dP[1+2s] and dP[0] are requested BEFORE the MFMA phase that precedes their use (clamped,
+// unpredicated loads), so no memory round trip sits between an MFMA phase and its stores.
 template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     using PB = PropBlock<NF, CT>;
@@ -338,56 +392,101 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
-    const int ldi = (int)p.ld;
+    float* __restrict__ D0 = p.base;
     float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
     const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
+    float* __restrict__ EX = p.extra;
+    const int row0 = 32 * w + 4 * kq;
+    const bool rows_in = 32 * w + 32 <= p.N;
     uint4 ah[KS], al[KS];
+    MCRN_TL(1, 0);
     PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    MCRN_TL(1, 1);
     const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
     for (int unit = u0; unit < u1; ++unit) {
-    const int colbase = unit * 32 * CT;
-    if (unit > u0) __syncthreads();
-    PB::stage(img, E2, p.ld, p.N, p.ncols, colbase, tid);
-    __syncthreads();
-    f32x16 acc[CT];
-    PB::mma(img, ah, al, acc, lane);
+        const int colbase = unit * 32 * CT;
+        int ld = (int)p.ld;
+        asm volatile("" : "+s"(ld));                   // see MCRN_ROW_OF
+        if (unit > u0) __syncthreads();
+        MCRN_TL(1, 2);
+        int nlast = p.N - 1;
+        MCRN_FRESH(ld); MCRN_FRESH(nlast);
+        PB::stage(img, E2, ld, nlast, p.ncols, colbase, tid);
+        MCRN_TL(1, 3);
+        MCRN_FRESH(ld);
+        f32x16 add[CT];                                // dP[1+2s] now, dP[0] (s = 0) for the second hop
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = colbase + 32 * t + cperm;
+        for (int t = 0; t < CT; ++t) {
+            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+            if (rows_in) {
+                const unsigned o = (unsigned)(row0 * ld + col);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N && col < p.ncols) {
-                const int off = r * ldi + col;   // < 2^31: one plane of a N <= 256 graph
-                const float d = acc[t][v] + D1[off];
-                acc[t][v] = d;
-                D1[off] = d;
+                for (int v = 0; v < 16; ++v) add[t][v] = D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
             } else {
-                acc[t][v] = 0.f;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) add[t][v] = D1[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
             }
         }
-    }
-    __syncthreads();
-    PB::to_img(img, acc, w, lane);
-    __syncthreads();
-    PB::mma(img, ah, al, acc, lane);
-    float* __restrict__ D0 = p.base;
-    float* __restrict__ EX = p.extra;
+        __syncthreads();
+        MCRN_TL(1, 4);
+        f32x16 acc[CT];
+        PB::mma(img, ah, al, acc, lane);
+        MCRN_FRESH(ld);
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = colbase + 32 * t + cperm;
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            const bool cok = col < p.ncols;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N && col < p.ncols) {
-                const int off = r * ldi + col;
-                if (s == 0) D0[off] = D0[off] + acc[t][v];
-                else EX[off] = acc[t][v];
+            for (int v = 0; v < 16; ++v) {
+                const bool ok = cok && (rows_in || row0 + MCRN_ROW_OF(v) < p.N);
+                const float d = ok ? acc[t][v] + add[t][v] : 0.f;     // zero rows / columns that do not exist
+                acc[t][v] = d;
+                if (ok) D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = d;
             }
         }
-    }
+        MCRN_FRESH(ld);
+        if (s == 0) {                                  // request dP[0] for the read-modify-write after hop 2
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+                if (rows_in) {
+                    const unsigned o = (unsigned)(row0 * ld + col);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) add[t][v] = D0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) add[t][v] = D0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
+                }
+            }
+        }
+        MCRN_TL(1, 5);
+        __syncthreads();
+        MCRN_TL(1, 6);
+        PB::to_img(img, acc, w, lane);
+        __syncthreads();
+        MCRN_TL(1, 7);
+        PB::mma(img, ah, al, acc, lane);
+        float* __restrict__ OUT = s == 0 ? D0 : EX;
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            if (col < p.ncols) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N)
+                        OUT[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = s == 0 ? add[t][v] + acc[t][v] : acc[t][v];
+            }
+        }
+        MCRN_TL(1, 8);
     }   // unit loop
+#ifdef MCRN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) g_tl[1][(blockIdx.y * gridDim.x + blockIdx.x) & 511][9] = wall_clock64();
+#endif
 }
 
 #define MCRN_NF_SWITCH(KERN, CT_, GRID, P)                                                   \

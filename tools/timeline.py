@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Measurement only: per-phase wall-clock timeline inside the fused propagation kernels.
+Needs the instrumented build:  make -C megacrn_amd/csrc timeline [FENCE=2]   then
+    MEGACRN_LIB=megacrn_amd/libmegacrn_hip_tl.so python tools/timeline.py [config] [eval|train]
+Stamps are the 100 MHz wall clock of thread 0 of each workgroup; the table shows, over the workgroups of the LAST
+launch of each kernel kind, the median / max time of every phase in microseconds."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import megacrn_amd  # noqa: E402
+from megacrn_amd._lib import lib  # noqa: E402
+from megacrn_amd.trainer import FlatTrainer  # noqa: E402
+
+PHASES = {
+    0: ["S frags", "x0c issue", "stage(load+cvt+lds)", "barrier", "mma1+X1 st", "barrier", "to_img+bar", "mma2+X2 st", "drain"],
+    1: ["S frags", "-", "stage(load+cvt+lds)", "barrier", "mma1+D1 rmw", "barrier", "to_img+bar", "mma2+D0 rmw", "drain"],
+}
+name = sys.argv[1] if len(sys.argv) > 1 else "metrla"
+mode = sys.argv[2] if len(sys.argv) > 2 else "train"
+cfg = bench.CONFIGS[name]
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+model = megacrn_amd.MegaCRN(cfg["N"], 1, 1, cfg["T"], cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(dev)
+x, yc, y = bench.synth(cfg, cfg["B"], 1234, dev)
+if mode == "train":
+    tr = FlatTrainer(model.train(), scaler_mean=54.4, scaler_std=19.5)
+    for _ in range(5):
+        tr.train_step(x, yc, y)
+else:
+    model.eval()
+    with torch.no_grad():
+        for _ in range(5):
+            model(x, yc)
+torch.cuda.synchronize()
+buf = np.zeros((3, 512, 12), dtype=np.uint64)
+lib.mcrn_debug_timeline.restype = C.c_int
+lib.mcrn_debug_timeline.argtypes = [C.c_void_p, C.c_size_t]
+assert lib.mcrn_debug_timeline(buf.ctypes.data, buf.nbytes) == 0
+for kind, names in PHASES.items():
+    t = buf[kind].astype(np.int64)
+    live = t[:, 0] > 0
+    if not live.any():
+        continue
+    t = t[live]
+    t0 = t[:, 0].min()
+    print(f"kind {kind}: {live.sum()} workgroups, first start -> last end {(t[:, 9].max() - t0) / 100:.2f} us, "
+          f"start skew (max-min) {(t[:, 0].max() - t0) / 100:.2f} us")
+    for i, nm in enumerate(names):
+        d = (t[:, i + 1] - t[:, i]) / 100.0
+        print(f"   {nm:22s} median {np.median(d):7.2f}  max {d.max():7.2f} us")
+    tot = (t[:, 9] - t[:, 0]) / 100.0
+    print(f"   {'workgroup total':22s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
