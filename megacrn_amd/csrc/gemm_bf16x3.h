@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
     constexpr int dbg = 0;
 #endif
 
+#ifdef MCRN_TIMELINE
+    unsigned long long tg_[6] = {0, 0, 0, 0, 0, 0}, tgt_ = wall_clock64();
+    const unsigned long long tg0_ = tgt_;
+#define MCRN_TG(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); tg_[i] += n_ - tgt_; tgt_ = n_; } } while (0)
+#else
+#define MCRN_TG(i)
+#endif
     TA ta;
     TB tb;
     ta.init(Ab, tid, m_blk, p.M, p.am, kbeg, p.ak.inner, akhi, p.ak.lo);
@@ -350,20 +357,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
         if (i < nt) MCRN_LOAD_TILE(ra[i], rb[i]);            // tiles 0 .. NS-1
     MCRN_STORE_TILE(ra[0], rb[0], 0);
     __syncthreads();
+    MCRN_TG(0);
     for (int t0 = 0; t0 < nt; t0 += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {                       // static register-set indices: set = tile % NS
             const int t = t0 + u;
             if (t >= nt) break;
             if (t + NS < nt && !(dbg & 2)) MCRN_LOAD_TILE(ra[u], rb[u]);   // set u held tile t (already in LDS) -> tile t+NS
+            MCRN_TG(1);
             // convert + store tile t+1 into the other LDS stage; independent of the MFMA block below, emitted
             // first so the scheduler can interleave its VALU/DS work with the matrix instructions
             if (t + 1 < nt && !(dbg & 4)) {
                 if (u & 1) MCRN_STORE_TILE(ra[(u + 1) % NS], rb[(u + 1) % NS], 0);
                 else MCRN_STORE_TILE(ra[(u + 1) % NS], rb[(u + 1) % NS], 1);
             }
+            MCRN_TG(2);
             if (!(dbg & 1)) { if (u & 1) MCRN_COMPUTE(1); else MCRN_COMPUTE(0); }   // NS is even: LDS stage = t & 1 = u & 1
+            MCRN_TG(3);
             if (!(dbg & 8)) __syncthreads();
+            MCRN_TG(4);
         }
     }
 #undef MCRN_LOAD_TILE
@@ -378,6 +390,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
                 for (int v = 0; v < 16; ++v) acc[i][j][v] += accA[i][j][v] + accB[i][j][v];
     }
     gemm_epilogue<FM, FN>(p, acc, batch, split, m_blk + wm * WM + 4 * kq, n_blk + wn * WN + l31);
+#ifdef MCRN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MCRN_TG(5);
+    if (tid == 0) {
+        unsigned long long* o = g_tl[3 + ROLE][(blockIdx.z * gridDim.x + blockIdx.x) & 511];
+        for (int i = 0; i < 6; ++i) o[i] = tg_[i];
+        o[6] = (unsigned long long)nt; o[7] = (unsigned long long)(BM * 1000 + BN); o[8] = tg0_; o[9] = tgt_;
+        o[10] = (unsigned long long)gridDim.x * gridDim.z;
+    }
+#endif
+#undef MCRN_TG
 }
 
 // ---- host launcher ------------------------------------------------------------------------

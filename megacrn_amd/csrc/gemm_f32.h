@@ -25,6 +25,21 @@ namespace mcrn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Measurement-only build (-DMCRN_TIMELINE=1|2, `make timeline [FENCE=2]`): thread 0 of every workgroup stamps the
+// 100 MHz wall clock at phase boundaries; =2 also drains the memory counters first so that a phase's
+// time includes the latency of what it issued.  kind 0 = prop2_fwd, 1 = prop2_bwd, 2 = ds_small,
+// 3 + ROLE = gemm_bf16x3_kernel (accumulated per-phase times of thread 0, see tools/timeline.py).
+#ifdef MCRN_TIMELINE
+__device__ unsigned long long g_tl[10][512][12];   // kinds 0-2: prop_small.h kernels; 3 + ROLE: tiled bf16x3 GEMM
+#define MCRN_TL(kind, i)                                                                            \
+    do {                                                                                            \
+        if (MCRN_TIMELINE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
+        if (threadIdx.x == 0) g_tl[kind][(blockIdx.y * gridDim.x + blockIdx.x) & 511][i] = wall_clock64(); \
+    } while (0)
+#else
+#define MCRN_TL(kind, i)
+#endif
+
 struct Dim2 {          // off(i) = (i / inner) * hi + (i % inner) * lo ; inner <= 0 means plain i*lo
     int inner;
     long long hi;
@@ -84,63 +99,118 @@ __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo
 }
 
 // ---- shared epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+// Loads never sit under a per-element branch: a fragment's 16 (or 32) operand loads are issued back to back from
+// clamped, always-valid addresses and only the stores are predicated.  (With `if (r < M) { load; ...; store }`
+// per element every load got its own basic block and a full memory round trip: 8.7 of 31.7 us per workgroup
+// in the weight-pool GEMM, measured with the in-kernel timeline.)  `rows_in` is wave-uniform.
+#define MCRN_EROW(v) (((v) & 3) + 8 * ((v) >> 2))
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], int batch, int split,
                                               int r_base, int c_base) {
     float* __restrict__ Cb = p.C[batch] + (long long)split * p.slab;
     const float* __restrict__ Cin = p.Cin[batch] ? p.Cin[batch] + (long long)split * p.slab : nullptr;
-#define MCRN_EPI_LOOP(BODY)                                                            \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                  \
-        const int c = c_base + j * 32;                                                 \
-        if (c < p.N) {                                                                 \
-            const long long co = d2off(p.cn.inner, p.cn.hi, p.cn.lo, c);               \
-            (void)co;                                                                  \
-            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                          \
-                _Pragma("unroll") for (int v = 0; v < 16; ++v) {                      \
-                    const int r = r_base + i * 32 + (v & 3) + 8 * (v >> 2);            \
-                    if (r < p.M) {                                                     \
-                        const float a = acc[i][j][v];                                  \
-                        BODY                                                           \
-                    }                                                                  \
-                }                                                                      \
-            }                                                                          \
-        }                                                                              \
+    const int rw = __builtin_amdgcn_readfirstlane(r_base - 4 * ((int)(threadIdx.x & 63) >> 5));   // first row of the wave's block
+    const int mlast = p.M - 1;
+    // One fragment (i, j) at a time.  `ld*` are re-read through an opaque move per fragment and a scheduling
+    // barrier closes it, so the address arithmetic of all FM*FN fragments is not hoisted in front of the first
+    // one (that spilled the accumulators at 128x128).
+#define MCRN_EPI_FRAGS(BODY)                                                                        \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                               \
+        const int c = c_base + j * 32;                                                              \
+        const bool cok = c < p.N;                                                                   \
+        const int cc = cok ? c : p.N - 1;                                                           \
+        (void)cc;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                           \
+            const int r0 = r_base + i * 32;                                                         \
+            const bool rows_in = rw + i * 32 + 32 <= p.M;                                           \
+            long long ld0 = LD0, ld1 = LD1, ld2 = LD2;                                              \
+            asm volatile("" : "+s"(ld0), "+s"(ld1), "+s"(ld2));                                     \
+            (void)ld1; (void)ld2;                                                                   \
+            BODY                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
     }
+    // row used for ADDRESSES (clamped into range) and the store predicate of accumulator register v
+#define MCRN_RA(v) (rows_in ? r0 + MCRN_EROW(v) : min(r0 + MCRN_EROW(v), mlast))
+#define MCRN_LIVE(v) (cok && (rows_in || r0 + MCRN_EROW(v) <= mlast))
     if (p.epi == EPI_STORE) {
+#define LD0 p.cm.lo
+#define LD1 0
+#define LD2 0
         if (Cin) {
-            MCRN_EPI_LOOP({
-                const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
-                Cb[off] = p.alpha * a + p.beta * Cin[off];
+            MCRN_EPI_FRAGS({
+                const long long co = d2off(p.cn.inner, p.cn.hi, p.cn.lo, cc);   /* C rows are always plain-strided */
+                float cin[16];
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) cin[v] = Cin[MCRN_RA(v) * ld0 + co];
+                _Pragma("unroll") for (int v = 0; v < 16; ++v)
+                    if (MCRN_LIVE(v)) Cb[(r0 + MCRN_EROW(v)) * ld0 + co] = p.alpha * acc[i][j][v] + p.beta * cin[v];
             })
         } else {
-            MCRN_EPI_LOOP({
-                const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
-                Cb[off] = p.alpha * a;
+            MCRN_EPI_FRAGS({
+                const long long co = d2off(p.cn.inner, p.cn.hi, p.cn.lo, cc);
+                _Pragma("unroll") for (int v = 0; v < 16; ++v)
+                    if (MCRN_LIVE(v)) Cb[(r0 + MCRN_EROW(v)) * ld0 + co] = p.alpha * acc[i][j][v];
             })
         }
     } else if (p.epi == EPI_BIAS) {
-        MCRN_EPI_LOOP({
-            const long long off = (long long)r * p.cm.lo + co;   /* C rows are always plain-strided */
-            Cb[off] = a + p.bias[c];
+        MCRN_EPI_FRAGS({
+            const long long co = d2off(p.cn.inner, p.cn.hi, p.cn.lo, cc);
+            const float bj = p.bias[cc];
+            _Pragma("unroll") for (int v = 0; v < 16; ++v)
+                if (MCRN_LIVE(v)) Cb[(r0 + MCRN_EROW(v)) * ld0 + co] = acc[i][j][v] + bj;
         })
+#undef LD0
+#undef LD1
+#undef LD2
     } else if (p.epi == EPI_GATE) {
         // z_r = sigmoid(AGCN_gate) ; candidate state input = z*h   (MegaCRN.py:43-45)
-        MCRN_EPI_LOOP({
-            const float g = 1.f / (1.f + expf(-(a + p.bias[c])));
-            Cb[(long long)r * (2 * p.H) + c] = g;
-            if (c < p.H) p.out2[(long long)r * p.out2_ld + c] = g * p.hsrc[(long long)r * p.hsrc_ld + c];
+#define LD0 (long long)(2 * p.H)
+#define LD1 p.hsrc_ld
+#define LD2 p.out2_ld
+        MCRN_EPI_FRAGS({
+            const float bj = p.bias[cc];
+            const bool isz = c < p.H;
+            const int ch = isz ? c : 0;
+            float h[16];
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) h[v] = p.hsrc[MCRN_RA(v) * ld1 + ch];
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) {
+                const float g = 1.f / (1.f + expf(-(acc[i][j][v] + bj)));
+                if (MCRN_LIVE(v)) {
+                    const int r = r0 + MCRN_EROW(v);
+                    Cb[r * ld0 + c] = g;
+                    if (isz) p.out2[r * ld2 + c] = g * h[v];
+                }
+            }
         })
+#undef LD0
     } else {
         // hc = tanh(AGCN_update) ; h' = r*h + (1-r)*hc               (MegaCRN.py:46-47)
-        MCRN_EPI_LOOP({
-            const float hc = tanhf(a + p.bias[c]);
-            Cb[(long long)r * p.H + c] = hc;
-            const float rg = p.zr[(long long)r * (2 * p.H) + p.H + c];
-            const float h = p.hsrc[(long long)r * p.hsrc_ld + c];
-            p.out2[(long long)r * p.out2_ld + c] = rg * h + (1.f - rg) * hc;
+#define LD0 (long long)p.H
+        MCRN_EPI_FRAGS({
+            const float bj = p.bias[cc];
+            float rg[16];
+            float h[16];
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) {
+                const int ra = MCRN_RA(v);
+                rg[v] = p.zr[ra * (2 * ld0) + ld0 + cc];
+                h[v] = p.hsrc[ra * ld1 + cc];
+            }
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) {
+                const float hc = tanhf(acc[i][j][v] + bj);
+                if (MCRN_LIVE(v)) {
+                    const int r = r0 + MCRN_EROW(v);
+                    Cb[r * ld0 + c] = hc;
+                    p.out2[r * ld2 + c] = rg[v] * h[v] + (1.f - rg[v]) * hc;
+                }
+            }
         })
+#undef LD0
+#undef LD1
+#undef LD2
     }
-#undef MCRN_EPI_LOOP
+#undef MCRN_RA
+#undef MCRN_LIVE
+#undef MCRN_EPI_FRAGS
 }
 
 // ---- operand tile: E rows (m or n) x 16 k ------------------------------------------------

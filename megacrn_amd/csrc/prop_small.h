@@ -251,20 +251,6 @@ struct PropBlock {
     }
 };
 
-// Measurement-only build (-DMCRN_TIMELINE=1|2, `make timeline [FENCE=2]`): thread 0 of every workgroup stamps the
-// 100 MHz wall clock at phase boundaries; =2 also drains the memory counters first so that a phase's
-// time includes the latency of what it issued.  kind 0 = prop2_fwd, 1 = prop2_bwd, 2 = ds_small.
-#ifdef MCRN_TIMELINE
-__device__ unsigned long long g_tl[3][512][12];
-#define MCRN_TL(kind, i)                                                                            \
-    do {                                                                                            \
-        if (MCRN_TIMELINE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
-        if (threadIdx.x == 0) g_tl[kind][(blockIdx.y * gridDim.x + blockIdx.x) & 511][i] = wall_clock64(); \
-    } while (0)
-#else
-#define MCRN_TL(kind, i)
-#endif
-
 struct Prop2P {
     const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
     float* base;                // plane set (Z for forward, dP for backward)
@@ -603,11 +589,22 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
             }
         }
     };
+#ifdef MCRN_TIMELINE
+    unsigned long long tl_acc[5] = {0, 0, 0, 0, 0}, tl_t = 0;
+#define MCRN_TLA(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); tl_acc[i] += n_ - tl_t; tl_t = n_; } } while (0)
+    MCRN_TL(2, 0);
+    if (threadIdx.x == 0) tl_t = wall_clock64();
+#else
+#define MCRN_TLA(i)
+#endif
     fetch(0);
     for (int pn = 0; pn < total; ++pn) {
         publish();                                           // panel pn: registers -> LDS image
+        MCRN_TLA(0);
         if (pn + 1 < total) fetch(pn + 1);                   // next panel's loads fly during the MFMA block
+        MCRN_TLA(1);
         __syncthreads();
+        MCRN_TLA(2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][lane]);
@@ -621,8 +618,11 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
             }
         }
+        MCRN_TLA(3);
         __syncthreads();                                     // image consumed before the next publish
+        MCRN_TLA(4);
     }
+    MCRN_TL(2, 1);
     float* __restrict__ C = p.C[sup] + (long long)z * p.slab;
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -640,6 +640,17 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
             }
         }
     }
+#ifdef MCRN_TIMELINE
+    MCRN_TL(2, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        unsigned long long* o = g_tl[2][(blockIdx.y * gridDim.x + blockIdx.x) & 511];
+        o[3] = wall_clock64();
+        for (int i = 0; i < 5; ++i) o[4 + i] = tl_acc[i];
+        o[9] = (unsigned long long)total;
+    }
+#endif
+#undef MCRN_TLA
 }
 static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st) {
     (void)hipGetLastError();

@@ -38,7 +38,7 @@ else:
         for _ in range(5):
             model(x, yc)
 torch.cuda.synchronize()
-buf = np.zeros((3, 512, 12), dtype=np.uint64)
+buf = np.zeros((10, 512, 12), dtype=np.uint64)
 lib.mcrn_debug_timeline.restype = C.c_int
 lib.mcrn_debug_timeline.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.mcrn_debug_timeline(buf.ctypes.data, buf.nbytes) == 0
@@ -55,4 +55,27 @@ for kind, names in PHASES.items():
         d = (t[:, i + 1] - t[:, i]) / 100.0
         print(f"   {nm:22s} median {np.median(d):7.2f}  max {d.max():7.2f} us")
     tot = (t[:, 9] - t[:, 0]) / 100.0
+    print(f"   {'workgroup total':22s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
+t = buf[2].astype(np.int64)
+t = t[t[:, 0] > 0]
+if len(t):
+    print(f"kind 2 (ds_small): {len(t)} workgroups, panels/workgroup median {int(np.median(t[:, 9]))}; first start -> last end {(t[:, 3].max() - t[:, 0].min()) / 100:.2f} us")
+    for nm, d in (("K loop", t[:, 1] - t[:, 0]), ("epilogue issue", t[:, 2] - t[:, 1]), ("epilogue drain", t[:, 3] - t[:, 2]),
+                  ("  sum publish", t[:, 4]), ("  sum fetch issue", t[:, 5]), ("  sum barrier 1", t[:, 6]), ("  sum mfma", t[:, 7]), ("  sum barrier 2", t[:, 8])):
+        print(f"   {nm:22s} median {np.median(d) / 100:7.2f}  max {d.max() / 100:7.2f} us")
+
+ROLES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
+for role in range(7):
+    t = buf[3 + role].astype(np.int64)
+    nblk = int(t[0, 10]) if t[0, 10] > 0 else 0
+    if nblk == 0:
+        continue
+    t = t[:min(nblk, 512)]
+    t = t[t[:, 8] > 0]
+    tile = int(t[0, 7])
+    print(f"GEMM role {ROLES[role]}: last launch {nblk} workgroups, tile {tile // 1000}x{tile % 1000}, K-tiles {int(np.median(t[:, 6]))}, "
+          f"first start -> last end {(t[:, 9].max() - t[:, 8].min()) / 100:.2f} us")
+    for i, nm in enumerate(["prologue", "sum load issue", "sum cvt+LDS store", "sum MFMA block", "sum barrier", "epilogue"]):
+        print(f"   {nm:22s} median {np.median(t[:, i]) / 100:7.2f}  max {t[:, i].max() / 100:7.2f} us")
+    tot = (t[:, 9] - t[:, 8]) / 100.0
     print(f"   {'workgroup total':22s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
