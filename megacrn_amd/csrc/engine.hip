@@ -603,6 +603,13 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
                         const SupBufs& o, const float* g1, const float* g2, long long ldg,
                         const float* dS1, const float* dS2, long long ldd, int nslab, long long slab,
                         float* dWe1, float* dWe2, float* dMem_acc, hipStream_t st) {
+    if (nslab > 16) {   // ~180 per-workgroup slabs of ds_small: fold them 8-wide at full-chip parallelism first (31 MB per support)
+        const int groups = 8;
+        const long long n = (long long)N * ldd;
+        LAUNCH(k_reduce_slabs_groups, dim3(cdiv(n, 256), groups), dim3(256), 0, st, const_cast<float*>(dS1), nslab, slab, n, groups);
+        LAUNCH(k_reduce_slabs_groups, dim3(cdiv(n, 256), groups), dim3(256), 0, st, const_cast<float*>(dS2), nslab, slab, n, groups);
+        nslab = groups;
+    }
     LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, dS1, ldd, nslab, slab, o.dLa, o.ldS, N);
     LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, dS2, ldd, nslab, slab, o.dLb, o.ldS, N);
     CKI(transpose(o.dLs, o.ldS, o.dLb, o.ldS, o.dLa, o.ldS, N, st));   // dLs = dL1 + dL2^T

@@ -528,6 +528,19 @@ __global__ void k_reduce_slabs(float* __restrict__ out, const float* __restrict_
     out[i] = accumulate ? out[i] + s : s;
 }
 
+// In-place first stage of a wide slab reduction: slab y (y < groups) becomes the sum of slabs y, y+groups, ...
+// Each slab y is read and written only by group y, in a fixed order (deterministic); the grid has `groups` times
+// more threads than elements so ~180 adjacency-gradient slabs stream at HBM rate instead of through N waves.
+__global__ void k_reduce_slabs_groups(float* __restrict__ slabs, int nslab, long long slab, long long n, int groups) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 4
+    for (int z = y; z < nslab; z += groups) s += slabs[z * slab + i];
+    slabs[y * slab + i] = s;
+}
+
 // strided 2-D copy:  dst[r*ldd + c] = src[r*lds + c]
 __global__ void k_copy2d(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
                          long long lds_, long long rows, int cols) {

@@ -492,12 +492,19 @@ static inline int pick_ct(int ncols, int ny) {
     const long long t2 = ((b2 + 255) / 256) * 2, t1 = ((b1 + 255) / 256) * 1;
     return t1 < t2 ? 1 : 2;
 }
+// Workgroups per support: both supports together must be resident at once on the 256 CUs (<= 128 each), and a
+// launch takes `passes` unit-times anyway, so use just enough workgroups for that many passes (136 units ->
+// 68 workgroups x 2 instead of 128 of which 8 do 2): same latency, ~half the CUs stay free for the side stream.
+static inline int prop2_blocks(int nunits) {
+    const int passes = (nunits + 127) / 128;
+    return (nunits + passes - 1) / passes;
+}
 static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     {
         const int nunits = (p.ncols + 63) / 64;
-        dim3 grid(nunits < 128 ? nunits : 128, 2);        // 2 supports x <= 128 = all workgroups resident on 256 CUs
+        dim3 grid(prop2_blocks(nunits), 2);
         MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p)
     }
     return hipGetLastError();
@@ -507,7 +514,7 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     const int NF = (p.N + 31) / 32;
     {
         const int nunits = (p.ncols + 63) / 64;
-        dim3 grid(nunits < 128 ? nunits : 128, 2);
+        dim3 grid(prop2_blocks(nunits), 2);
         MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p)
     }
     return hipGetLastError();
