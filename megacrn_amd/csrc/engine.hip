@@ -519,17 +519,32 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
     return 0;
 }
 
+// do_a / do_c: the model's BPTT loops fuse C of step t+1 with A of step t (cell_bwd_ca below) and skip them here
 static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float* Y, const float* zr,
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
-                         float* dTg = nullptr) {
+                         float* dTg = nullptr, bool do_a = true, bool do_c = true, bool* xu_out = nullptr,
+                         bool* xg_out = nullptr) {
     const long long RH = s.R * s.H;
     bool xu = false, xg = false;
-    LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
+    if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg));
-    LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    if (xu_out) *xu_out = xu;
+    if (xg_out) *xg_out = xg;
+    return 0;
+}
+// C of the step just finished (its planes dP / dQ, extra planes dTu / dTg when xu / xg) + projection backward
+// (decoder: Wp != null) + A of the next step to process (saved Z / zr / hc of that step)
+static int cell_bwd_ca(const Shp& s, const float* dP, const float* dQ, const float* dTu, const float* dTg, bool xu, bool xg,
+                       const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
+                       float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
+                       float* dacc, hipStream_t st) {
+    LAUNCH(k_cell_bwd_ca, dim3(cdiv(s.R * s.H, 256)), dim3(256), 0, st, dQ, (const float*)(xg ? dTg : nullptr), dP,
+           (const float*)(xu ? dTu : nullptr), (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
+           Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     return 0;
 }
 
@@ -985,17 +1000,29 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
     Sup ud = u; ud.defer = P.defer_ds;
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
-    for (int t = To - 1; t >= 0; --t) {
-        const bool last = t == To - 1;
-        const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
-        LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
-               (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
-               p->proj_w, Hd, od, B, N, last ? (const float*)nullptr : (const float*)P.dacc_d, P.dhn_d,
-               P.dgo + (long long)t * R * od);
-        CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
-                          wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd,
-                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dP,
-                          P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ, P.dacc_d, P.dxin_d, st, P.dTu, P.dTg));
+    {
+        bool xu = false, xg = false;
+        const float *dPprev = nullptr, *dQprev = nullptr;
+        for (int t = To - 1; t >= 0; --t) {
+            const bool last = t == To - 1;
+            const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
+            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dP;
+            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ;
+            if (last) {
+                LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
+                       (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
+                       p->proj_w, Hd, od, B, N, (const float*)nullptr, P.dhn_d, P.dgo + (long long)t * R * od);
+            } else {   // C(t+1) + projection backward(t) + A(t) in one launch
+                CKI(cell_bwd_ca(sd, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
+                                (long long)To * N * od, (long long)od, use_next, p->proj_w, od, P.dgo + (long long)t * R * od,
+                                P.Zdec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
+                                P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st));
+            }
+            CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
+                              wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
+                              P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg));
+            dPprev = dPt; dQprev = dQt;
+        }
     }
     // Decoder weight/bias/projection gradients depend only on the finished decoder BPTT: run them on the
     // helper stream so they overlap the memory-head and encoder backward below (joined before the adjacency
@@ -1039,10 +1066,19 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
            (long long)H * D, (long long)H * D, 0);
     // ---- encoder BPTT
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
-    for (int t = Ti - 1; t >= 0; --t)
-        CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
-                          P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
-                          P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg));
+    {
+        bool xu = false, xg = false;
+        for (int t = Ti - 1; t >= 0; --t) {
+            const bool first = t == Ti - 1;
+            if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
+                CKI(cell_bwd_ca(se, P.dP, P.dQ, P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
+                                P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
+                                P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
+            CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
+                              P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
+                              P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg));
+        }
+    }
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
     CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st));
     CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st));

@@ -482,6 +482,48 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
     }
 }
 
+// C(step t+1) + [decoder: projection backward of step t] + A(step t) in ONE launch: the three are element-wise over
+// the same (row, state channel) grid and adjacent in the BPTT loop, so interior steps save two launches per cell
+// (the decoder-input gradient dxin[r][j] that the projection needs is recomputed from the four plane entries).
+//   dh      = dacc + dZ0[state]                                    (C)
+//   dgo_j   = d_out[b,t,n,j] + (use_next ? dY0[in j] + dZ0[in j] : 0) ; dh += sum_j dgo_j Wp[j][c]   (k_proj_bwd)
+//   dU, dG[:,H:], dacc from dh and step t's saved z0 / zr / hc     (A)
+__global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __restrict__ dz0x,
+                              const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ld,
+                              const float* __restrict__ dout_bt, long long out_sb, long long out_sn, int use_next,
+                              const float* __restrict__ Wp, int od, float* __restrict__ dgo_rows, int B,
+                              const float* __restrict__ z0, long long ldz, const float* __restrict__ zr,
+                              const float* __restrict__ hc, int H, long long R,
+                              float* __restrict__ dU, float* __restrict__ dG, float* __restrict__ dacc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * H) return;
+    const int c = (int)(i % H);
+    const long long r = i / H;
+    float a = dz0[r * ld + c];
+    if (dz0x) a += dz0x[r * ld + c];
+    float g = dacc[i] + a;
+    if (Wp) {
+        const int n = (int)(r / B), b = (int)(r % B);
+        for (int j = 0; j < od; ++j) {
+            float go = dout_bt[b * out_sb + n * out_sn + j];
+            if (use_next) {
+                float x = dz0[r * ld + H + j] + dy0[r * ld + H + j];
+                if (dz0x) x += dz0x[r * ld + H + j];
+                if (dy0x) x += dy0x[r * ld + H + j];
+                go += x;
+            }
+            g += go * Wp[(long long)j * H + c];
+            if (c == 0) dgo_rows[r * od + j] = go;
+        }
+    }
+    const float h = z0[r * ldz + c];
+    const float rr = zr[r * 2 * H + H + c];
+    const float hv = hc[i];
+    dU[i] = g * (1.f - rr) * (1.f - hv * hv);
+    dG[r * 2 * H + H + c] = g * (h - hv) * rr * (1.f - rr);
+    dacc[i] = g * rr;
+}
+
 // ---------------------------------------------------------------------------------------------
 // deterministic column sums:  out[c] (+)= sum_r w[r]*X[r*ld + c]   (w nullable), two stages
 // ---------------------------------------------------------------------------------------------
