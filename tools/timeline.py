@@ -18,8 +18,9 @@ from megacrn_amd._lib import lib  # noqa: E402
 from megacrn_amd.trainer import FlatTrainer  # noqa: E402
 
 PHASES = {
-    0: ["S frags", "x0c issue", "stage(load+cvt+lds)", "barrier", "mma1+X1 st", "barrier", "to_img+bar", "mma2+X2 st", "drain"],
-    1: ["S frags", "-", "stage(load+cvt+lds)", "barrier", "mma1+D1 rmw", "barrier", "to_img+bar", "mma2+D0 rmw", "drain"],
+    # (a workgroup that walks 2 units overwrites its stamps: its "unit setup" then contains the whole first unit)
+    0: ["S frags", "unit setup", "stage(load+cvt+lds)", "x0 prefetch + barrier", "mma1 + X1 stores", "barrier", "to_img + barrier", "mma2 + X2 stores", "drain"],
+    1: ["S frags", "unit setup", "stage(load+cvt+lds)", "dP[1+2s] prefetch + barrier", "mma1 + dP[1+2s] stores + dP[0] prefetch", "barrier", "to_img + barrier", "mma2 + dP[0] stores", "drain"],
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "metrla"
 mode = sys.argv[2] if len(sys.argv) > 2 else "train"
@@ -53,16 +54,16 @@ for kind, names in PHASES.items():
           f"start skew (max-min) {(t[:, 0].max() - t0) / 100:.2f} us")
     for i, nm in enumerate(names):
         d = (t[:, i + 1] - t[:, i]) / 100.0
-        print(f"   {nm:22s} median {np.median(d):7.2f}  max {d.max():7.2f} us")
+        print(f"   {nm:40s} median {np.median(d):7.2f}  max {d.max():7.2f} us")
     tot = (t[:, 9] - t[:, 0]) / 100.0
-    print(f"   {'workgroup total':22s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
+    print(f"   {'workgroup total':40s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
 t = buf[2].astype(np.int64)
 t = t[t[:, 0] > 0]
 if len(t):
     print(f"kind 2 (ds_small): {len(t)} workgroups, panels/workgroup median {int(np.median(t[:, 9]))}; first start -> last end {(t[:, 3].max() - t[:, 0].min()) / 100:.2f} us")
     for nm, d in (("K loop", t[:, 1] - t[:, 0]), ("epilogue issue", t[:, 2] - t[:, 1]), ("epilogue drain", t[:, 3] - t[:, 2]),
                   ("  sum publish", t[:, 4]), ("  sum fetch issue", t[:, 5]), ("  sum barrier 1", t[:, 6]), ("  sum mfma", t[:, 7]), ("  sum barrier 2", t[:, 8])):
-        print(f"   {nm:22s} median {np.median(d) / 100:7.2f}  max {d.max() / 100:7.2f} us")
+        print(f"   {nm:40s} median {np.median(d) / 100:7.2f}  max {d.max() / 100:7.2f} us")
 
 ROLES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
 for role in range(7):
@@ -76,6 +77,6 @@ for role in range(7):
     print(f"GEMM role {ROLES[role]}: last launch {nblk} workgroups, tile {tile // 1000}x{tile % 1000}, K-tiles {int(np.median(t[:, 6]))}, "
           f"first start -> last end {(t[:, 9].max() - t[:, 8].min()) / 100:.2f} us")
     for i, nm in enumerate(["prologue", "sum load issue", "sum cvt+LDS store", "sum MFMA block", "sum barrier", "epilogue"]):
-        print(f"   {nm:22s} median {np.median(t[:, i]) / 100:7.2f}  max {t[:, i].max() / 100:7.2f} us")
+        print(f"   {nm:40s} median {np.median(t[:, i]) / 100:7.2f}  max {t[:, i].max() / 100:7.2f} us")
     tot = (t[:, 9] - t[:, 8]) / 100.0
-    print(f"   {'workgroup total':22s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
+    print(f"   {'workgroup total':40s} median {np.median(tot):7.2f}  max {tot.max():7.2f} us")
