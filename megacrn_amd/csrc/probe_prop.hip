@@ -9,6 +9,8 @@
 namespace mcrn {
 template __global__ void prop2_fwd_kernel<7, 2>(const Prop2P);
 template __global__ void prop2_bwd_kernel<7, 2>(const Prop2P);
+template __global__ void prop2_fwd_kernel<7, 3>(const Prop2P);
+template __global__ void prop2_bwd_kernel<7, 3>(const Prop2P);
 template __global__ void prop_small_kernel<7>(const PropP);
 template __global__ void ds_small_kernel<7>(const DsP);
 template __global__ void gemm_bf16x3_kernel<64, 64, 2, 2, true, false, ROLE_WP>(const GemmP);

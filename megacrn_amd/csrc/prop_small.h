@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NF) void prop_small_kernel(const PropP p) {
 // straight into the next B image (each lane owns 4 consecutive rows = one 8-byte half of a B-fragment
 // vector) and S stays in registers for both hops.
 // ---------------------------------------------------------------------------------------------
-template <int NF, int CT>      // CT = 32-column tiles per workgroup (1 or 2)
+template <int NF, int CT>      // CT = 32-column tiles per workgroup unit (1, 2 or 3)
 struct PropBlock {
     static constexpr int KS = 2 * NF;
     static constexpr int IMG = CT * KS * 2 * 64;     // uint4
@@ -155,29 +155,34 @@ struct PropBlock {
     // round trip each.  Offsets are 32-bit: base lane offset + scalar multiples of the row stride.
     static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, int ld, int nlast /* N-1 */,
                                                  int ncols, int colbase, int tid) {
-        const int cg = tid % (8 * CT), kg = tid / (8 * CT);
-        if (kg >= 4 * NF) return;                     // CT == 1: half of the threads have no item
-        const int col = colbase + 4 * cg;
-        const bool cv = col < ncols;                  // ncols % 4 == 0: a float4 is all-in or all-out
-        const int colc = cv ? col : 0;
-        float v[8][4];
+        // items = (8*CT column quads) x (4*NF k-groups); CT == 1: half of the threads have no item, CT == 3: a second round
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = 8 * kg + i;
-            const float4 t = *reinterpret_cast<const float4*>(X + (unsigned)(min(k, nlast) * ld + colc));
-            const bool ok = k <= nlast;
-            v[i][0] = ok ? t.x : 0.f; v[i][1] = ok ? t.y : 0.f; v[i][2] = ok ? t.z : 0.f; v[i][3] = ok ? t.w : 0.f;
-        }
-        const int ct = cg >> 3, ks = kg >> 1, kqq = kg & 1;
+        for (int it0 = 0; it0 < 8 * CT * 4 * NF; it0 += 64 * NF) {
+            const int it = it0 + tid;
+            if (it >= 8 * CT * 4 * NF) break;
+            const int cg = it % (8 * CT), kg = it / (8 * CT);
+            const int col = colbase + 4 * cg;
+            const bool cv = col < ncols;              // ncols % 4 == 0: a float4 is all-in or all-out
+            const int colc = cv ? col : 0;
+            float v[8][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float col8[8] = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
-            uint4 h, l;
-            split8(col8, h, l);
-            if (!cv) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
-            const int slot = c * 8 + (cg & 7) + 32 * kqq;
-            img[((ct * KS + ks) * 2 + 0) * 64 + slot] = h;
-            img[((ct * KS + ks) * 2 + 1) * 64 + slot] = l;
+            for (int i = 0; i < 8; ++i) {
+                const int k = 8 * kg + i;
+                const float4 t = *reinterpret_cast<const float4*>(X + (unsigned)(min(k, nlast) * ld + colc));
+                const bool ok = k <= nlast;
+                v[i][0] = ok ? t.x : 0.f; v[i][1] = ok ? t.y : 0.f; v[i][2] = ok ? t.z : 0.f; v[i][3] = ok ? t.w : 0.f;
+            }
+            const int ct = cg >> 3, ks = kg >> 1, kqq = kg & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float col8[8] = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
+                uint4 h, l;
+                split8(col8, h, l);
+                if (!cv) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
+                const int slot = c * 8 + (cg & 7) + 32 * kqq;
+                img[((ct * KS + ks) * 2 + 0) * 64 + slot] = h;
+                img[((ct * KS + ks) * 2 + 1) * 64 + slot] = l;
+            }
         }
     }
     static __device__ __forceinline__ void load_a(const uint4* __restrict__ sfw, uint4 (&ah)[KS], uint4 (&al)[KS]) {
@@ -188,33 +193,39 @@ struct PropBlock {
         }
     }
     // acc[t] = A x img[t].  Independent accumulator chains hide the MFMA dependent-issue latency:
-    // CT == 2: the two column tiles; CT == 1: the three split products, summed at the end.
+    // CT >= 2: the column tiles; CT == 1: the three split products, summed at the end.
+    // INIT: acc already holds the addend (loaded straight into the accumulator registers: costs no extra VGPRs)
+    template <bool INIT = false>
     static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[KS], const uint4 (&al)[KS],
                                                f32x16 (&acc)[CT], int lane) {
-        if constexpr (CT == 2) {
+        if constexpr (CT >= 2) {
+            if constexpr (!INIT) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+                    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
                 const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
-                const bf16x8 b0h = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 0) * 64 + lane]);
-                const bf16x8 b0l = __builtin_bit_cast(bf16x8, img[((0 * KS + ks) * 2 + 1) * 64 + lane]);
-                const bf16x8 b1h = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 0) * 64 + lane]);
-                const bf16x8 b1l = __builtin_bit_cast(bf16x8, img[((1 * KS + ks) * 2 + 1) * 64 + lane]);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b0h, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, b1h, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0l, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1l, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b0h, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, b1h, acc[1], 0, 0, 0);
+                bf16x8 bh[CT], bl[CT];
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    bh[t] = __builtin_bit_cast(bf16x8, img[((t * KS + ks) * 2 + 0) * 64 + lane]);
+                    bl[t] = __builtin_bit_cast(bf16x8, img[((t * KS + ks) * 2 + 1) * 64 + lane]);
+                }
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[t], acc[t], 0, 0, 0);
             }
         } else {
             f32x16 a0, a1, a2;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { a0[v] = 0.f; a1[v] = 0.f; a2[v] = 0.f; }
+            for (int v = 0; v < 16; ++v) { a0[v] = 0.f; a1[v] = 0.f; a2[v] = INIT ? acc[0][v] : 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
@@ -300,26 +311,11 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         if (unit > u0) __syncthreads();                // previous unit's hop-2 image fully consumed
         MCRN_TL(0, 2);
         int nlast = p.N - 1;
+        int tidv = tid;
         MCRN_FRESH(ld); MCRN_FRESH(nlast);              // nothing the loads need is hoisted out of the unit loop (and spilled)
-        PB::stage(img, X0, ld, nlast, p.ncols, colbase, tid);
+        asm volatile("" : "+v"(tidv));                  // ... nor the per-thread LDS store addresses of the staging
+        PB::stage(img, X0, ld, nlast, p.ncols, colbase, tidv);
         MCRN_TL(0, 3);
-        // x0 in accumulator layout for the final "2 S x1 - x0": requested here (the staging registers are free
-        // again and the lines were just staged, so these are cache hits), consumed after both hops.
-        // Clamped addresses, no predicate: out-of-range elements are never stored.
-        MCRN_FRESH(ld);
-        f32x16 x0c[CT];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
-            if (rows_in) {
-                const unsigned o = (unsigned)(row0 * ld + col);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) x0c[t][v] = X0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
-            } else {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) x0c[t][v] = X0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
-            }
-        }
         __syncthreads();
         MCRN_TL(0, 4);
         f32x16 acc[CT];
@@ -340,9 +336,29 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         __syncthreads();                               // every wave finished reading the hop-1 image
         MCRN_TL(0, 6);
         PB::to_img(img, acc, w, lane);
+        // x2 = 2 S x1 - x0 = 2 (S x1 - x0/2): x0 is loaded STRAIGHT INTO the accumulators (dead after to_img) as the
+        // initial value of hop 2 - no extra registers, and the loads (cache hits: the lines were staged) fly during the
+        // barrier.  Clamped addresses, no predicate: out-of-range elements are never stored.
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+            if (rows_in) {
+                const unsigned o = (unsigned)(row0 * ld + col);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = X0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = X0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
+            }
+        }
         __syncthreads();
         MCRN_TL(0, 7);
-        PB::mma(img, ah, al, acc, lane);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] *= -0.5f;
+        PB::template mma<true>(img, ah, al, acc, lane);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
             if (col < p.ncols) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X2[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = 2.f * acc[t][v] - x0c[t][v];
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X2[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = 2.f * acc[t][v];
             }
         }
         MCRN_TL(0, 8);
@@ -367,8 +383,8 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
 //   s = 0:  dP[0] += S_1^T d1t_1        (read-modify-write)
 //   s = 1:  extra  = S_2^T d1t_2        (plain store; the consumers of dP[0] add it)
 // Each element has exactly one writer, so the result is deterministic while both supports run on different CUs.
-// The addends dP[1+2s] and dP[0] are requested BEFORE the MFMA phase that precedes their use (clamped,
-// unpredicated loads), so no memory round trip sits between an MFMA phase and its stores.
+// The addends dP[1+2s] and dP[0] are loaded (clamped, unpredicated) straight into the accumulators before the MFMA
+// chain that adds to them, so no memory round trip sits between an MFMA phase and its stores.
 template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     using PB = PropBlock<NF, CT>;
@@ -397,27 +413,33 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         if (unit > u0) __syncthreads();
         MCRN_TL(1, 2);
         int nlast = p.N - 1;
+        int tidv = tid;
         MCRN_FRESH(ld); MCRN_FRESH(nlast);
-        PB::stage(img, E2, ld, nlast, p.ncols, colbase, tid);
+        asm volatile("" : "+v"(tidv));
+        PB::stage(img, E2, ld, nlast, p.ncols, colbase, tidv);
         MCRN_TL(1, 3);
-        MCRN_FRESH(ld);
-        f32x16 add[CT];                                // dP[1+2s] now, dP[0] (s = 0) for the second hop
+        // The addends (dP[1+2s] for hop 1, dP[0] for hop 2 of support 0) are loaded STRAIGHT INTO the accumulators as
+        // the MFMA chain's initial value: no extra registers, and the loads fly during the barrier that follows.
+        auto load_acc = [&](const float* __restrict__ src, f32x16 (&dst)[CT], int ldv) {
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
-            if (rows_in) {
-                const unsigned o = (unsigned)(row0 * ld + col);
+            for (int t = 0; t < CT; ++t) {
+                const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+                if (rows_in) {
+                    const unsigned o = (unsigned)(row0 * ldv + col);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) add[t][v] = D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
-            } else {
+                    for (int v = 0; v < 16; ++v) dst[t][v] = src[o + (unsigned)(MCRN_ROW_OF(v) * ldv)];
+                } else {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) add[t][v] = D1[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
+                    for (int v = 0; v < 16; ++v) dst[t][v] = src[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ldv + col)];
+                }
             }
-        }
+        };
+        f32x16 acc[CT];
+        MCRN_FRESH(ld);
+        load_acc(D1, acc, ld);
         __syncthreads();
         MCRN_TL(1, 4);
-        f32x16 acc[CT];
-        PB::mma(img, ah, al, acc, lane);
+        PB::template mma<true>(img, ah, al, acc, lane);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -427,33 +449,27 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const bool ok = cok && (rows_in || row0 + MCRN_ROW_OF(v) < p.N);
-                const float d = ok ? acc[t][v] + add[t][v] : 0.f;     // zero rows / columns that do not exist
+                const float d = ok ? acc[t][v] : 0.f;                 // zero rows / columns that do not exist
                 acc[t][v] = d;
                 if (ok) D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = d;
-            }
-        }
-        MCRN_FRESH(ld);
-        if (s == 0) {                                  // request dP[0] for the read-modify-write after hop 2
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
-                if (rows_in) {
-                    const unsigned o = (unsigned)(row0 * ld + col);
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) add[t][v] = D0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) add[t][v] = D0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
-                }
             }
         }
         MCRN_TL(1, 5);
         __syncthreads();
         MCRN_TL(1, 6);
         PB::to_img(img, acc, w, lane);
+        MCRN_FRESH(ld);
+        if (s == 0) {
+            load_acc(D0, acc, ld);
+        } else {
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        }
         __syncthreads();
         MCRN_TL(1, 7);
-        PB::mma(img, ah, al, acc, lane);
+        PB::template mma<true>(img, ah, al, acc, lane);
         float* __restrict__ OUT = s == 0 ? D0 : EX;
         MCRN_FRESH(ld);
 #pragma unroll
@@ -463,8 +479,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
             if (col < p.ncols) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N)
-                        OUT[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = s == 0 ? add[t][v] + acc[t][v] : acc[t][v];
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) OUT[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = acc[t][v];
             }
         }
         MCRN_TL(1, 8);
@@ -492,31 +507,34 @@ static inline int pick_ct(int ncols, int ny) {
     const long long t2 = ((b2 + 255) / 256) * 2, t1 = ((b1 + 255) / 256) * 1;
     return t1 < t2 ? 1 : 2;
 }
-// Workgroups per support: both supports together must be resident at once on the 256 CUs (<= 128 each), and a
-// launch takes `passes` unit-times anyway, so use just enough workgroups for that many passes (136 units ->
-// 68 workgroups x 2 instead of 128 of which 8 do 2): same latency, ~half the CUs stay free for the side stream.
-static inline int prop2_blocks(int nunits) {
-    const int passes = (nunits + 127) / 128;
-    return (nunits + passes - 1) / passes;
+// Unit width and workgroups per support.  Both supports together must be resident at once on the 256 CUs (<= 128
+// workgroups each) and a launch costs `passes` unit-times, so: 64-column units when they fit in one pass; else
+// 96-column units if THOSE fit in one pass (METR-LA decoder: 136 -> 91 units, ~22 us instead of 2 x 16 us); else
+// 64-column units over just enough workgroups for the pass count (the rest of the CUs stay free for the side stream).
+static inline void prop2_shape(int ncols, int& ct, int& blocks) {
+    const int u2 = (ncols + 63) / 64, u3 = (ncols + 95) / 96;
+    if (u2 > 128 && u3 <= 128) { ct = 3; blocks = u3; return; }
+    const int passes = (u2 + 127) / 128;
+    ct = 2; blocks = (u2 + passes - 1) / passes;
 }
 static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
-    {
-        const int nunits = (p.ncols + 63) / 64;
-        dim3 grid(prop2_blocks(nunits), 2);
-        MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p)
-    }
+    int ct, blocks;
+    prop2_shape(p.ncols, ct, blocks);
+    dim3 grid(blocks, 2);
+    if (ct == 3) { MCRN_NF_SWITCH(prop2_fwd_kernel, 3, grid, p) }
+    else { MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p) }
     return hipGetLastError();
 }
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
-    {
-        const int nunits = (p.ncols + 63) / 64;
-        dim3 grid(prop2_blocks(nunits), 2);
-        MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p)
-    }
+    int ct, blocks;
+    prop2_shape(p.ncols, ct, blocks);
+    dim3 grid(blocks, 2);
+    if (ct == 3) { MCRN_NF_SWITCH(prop2_bwd_kernel, 3, grid, p) }
+    else { MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p) }
     return hipGetLastError();
 }
 
