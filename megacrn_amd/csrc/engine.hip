@@ -618,7 +618,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
                         const SupBufs& o, const float* g1, const float* g2, long long ldg,
                         const float* dS1, const float* dS2, long long ldd, int nslab, long long slab,
                         float* dWe1, float* dWe2, float* dMem_acc, hipStream_t st) {
-    if (nslab > 16) {   // ~180 per-workgroup slabs of ds_small: fold them 8-wide at full-chip parallelism first (31 MB per support)
+    if (nslab > 16) {   // 64 per-workgroup slabs of ds_small: fold them 8-wide at full-chip parallelism first (11 MB per support)
         const int groups = 8;
         const long long n = (long long)N * ldd;
         LAUNCH(k_reduce_slabs_groups, dim3(cdiv(n, 256), groups), dim3(256), 0, st, const_cast<float*>(dS1), nslab, slab, n, groups);

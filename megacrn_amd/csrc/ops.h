@@ -572,7 +572,7 @@ __global__ void k_reduce_slabs(float* __restrict__ out, const float* __restrict_
 
 // In-place first stage of a wide slab reduction: slab y (y < groups) becomes the sum of slabs y, y+groups, ...
 // Each slab y is read and written only by group y, in a fixed order (deterministic); the grid has `groups` times
-// more threads than elements so ~180 adjacency-gradient slabs stream at HBM rate instead of through N waves.
+// more threads than elements so the 64 adjacency-gradient slabs stream at HBM rate instead of through N waves.
 __global__ void k_reduce_slabs_groups(float* __restrict__ slabs, int nslab, long long slab, long long n, int groups) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;

@@ -62,7 +62,7 @@ t = t[t[:, 0] > 0]
 if len(t):
     print(f"kind 2 (ds_small): {len(t)} workgroups, panels/workgroup median {int(np.median(t[:, 9]))}; first start -> last end {(t[:, 3].max() - t[:, 0].min()) / 100:.2f} us")
     for nm, d in (("K loop", t[:, 1] - t[:, 0]), ("epilogue issue", t[:, 2] - t[:, 1]), ("epilogue drain", t[:, 3] - t[:, 2]),
-                  ("  sum publish", t[:, 4]), ("  sum fetch issue", t[:, 5]), ("  sum barrier 1", t[:, 6]), ("  sum mfma", t[:, 7]), ("  sum barrier 2", t[:, 8])):
+                  ("  sum loop top", t[:, 4]), ("  sum publish next", t[:, 5]), ("  sum fetch issue", t[:, 6]), ("  sum mfma", t[:, 7]), ("  sum barrier", t[:, 8])):
         print(f"   {nm:40s} median {np.median(d) / 100:7.2f}  max {d.max() / 100:7.2f} us")
 
 ROLES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
