@@ -41,3 +41,20 @@ for s, e, k, _ in rows:
     pern[k.split("(")[0][-70:]][1] += 1
 for k, (v, c) in sorted(pern.items(), key=lambda kv: -kv[1][0])[:22]:
     print(f"{100*v/span:5.1f}%  {v/c/1e3:8.1f} us x {c:5d}  {k}")
+
+# per-queue view: idle time between consecutive kernels of the busiest queue, grouped by (previous -> next) kernel
+import re as _re
+qmain = max(perq, key=perq.get)
+seq = sorted([r for r in rows if r[3] == qmain])
+pair = defaultdict(lambda: [0, 0])
+short = lambda k: _re.sub(r"^void ", "", k.split("(")[0]).replace("mcrn::", "")[:44]
+tot_gap = 0
+for a, b_ in zip(seq, seq[1:]):
+    g_ = b_[0] - a[1]
+    if g_ > 0:
+        pair[(short(a[2]), short(b_[2]))][0] += g_
+        pair[(short(a[2]), short(b_[2]))][1] += 1
+        tot_gap += g_
+print(f"queue {qmain}: idle between its own kernels {tot_gap/1e6:.2f} ms ({100*tot_gap/span:.1f}% of span); top (prev -> next):")
+for (a, b_), (v, c) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {100*v/span:4.1f}%  {v/c/1e3:7.1f} us x {c:4d}  {a} -> {b_}")
