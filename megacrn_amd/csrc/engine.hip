@@ -15,12 +15,14 @@
 #include <string.h>
 #include <math.h>
 #include <map>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "../../include/megacrn_hip.h"
 #include "gemm_f32.h"
 #include "gemm_bf16x3.h"
 #include "prop_small.h"
+#include "dgrad_stream.h"
 #include "ops.h"
 
 namespace mcrn {
@@ -351,7 +353,13 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     if (used_dT) *used_dT = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
-    {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
+    if (imgd && g_precision == MCRN_BF16X3 && dgrad_stream_ok(O) && aligned16(dY)) {
+        // d-grad, streaming form (dgrad_stream.h): imgd is the B-fragment image of Wd (built by wprep under the same test)
+        DgradP q;
+        q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp;
+        const double fl = 2.0 * (double)s.R * O * (double)(s.G * s.Cp);
+        MCRN_PROF_WRAP(ROLE_DGRAD, launch_dgrad_stream(q, st), fl, 2.0 * (double)s.R * O * (double)(s.G * s.C));
+    } else {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
         GemmP p = gp();
         p.M = (int)s.R; p.N = s.G * s.Cp; p.K = O;
         p.A[0] = dY; p.am = plain(O); p.ak = plain(1);
@@ -696,7 +704,11 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
             const long long n = (long long)((Kp + 31) / 32) * 4 * npad;
             LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wf, (long long)O, 1LL, Kp, O, npad, 0, imgf);
         }
-        {   // d-grad: B[k = o][n = k'] = Wd[k'*O + o]
+        if (dgrad_stream_ok(O)) {   // d-grad, streaming kernel: Wd [(g,c')][o] in MFMA B-fragment order
+            const int KS = O / 16;
+            const long long tot = (long long)((Kp + 31) / 32) * KS * 64;
+            LAUNCH(k_wfrag_build, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)Wd, (long long)O, Kp, O, KS, imgd, tot);
+        } else {   // d-grad, tiled GEMM: B[k = o][n = k'] = Wd[k'*O + o]
             const int npad = (Kp + 3) & ~3;
             const long long n = (long long)((O + 31) / 32) * 4 * npad;
             LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wd, 1LL, (long long)O, O, Kp, npad, 1, imgd);
@@ -771,7 +783,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.Wd[i] = b.take<float>(n);
         P.dWs[i] = b.take<float>(n * NSLAB_W);
         P.imgf[i] = b.take<uint4>(bimg_uint4(sh[i]->G * sh[i]->Cp, Os[i]));
-        P.imgd[i] = b.take<uint4>(bimg_uint4(Os[i], sh[i]->G * sh[i]->Cp));
+        P.imgd[i] = b.take<uint4>(std::max(bimg_uint4(Os[i], sh[i]->G * sh[i]->Cp), wfrag_uint4(sh[i]->G * sh[i]->Cp, Os[i])));
     }
     const long long R = P.se.R;
     P.Zenc = b.take<float>((size_t)(d->T_in + 1) * P.se.ZT);

@@ -6,6 +6,7 @@
 #include "gemm_f32.h"
 #include "gemm_bf16x3.h"
 #include "prop_small.h"
+#include "dgrad_stream.h"
 namespace mcrn {
 template __global__ void prop2_fwd_kernel<7, 2>(const Prop2P);
 template __global__ void prop2_bwd_kernel<7, 2>(const Prop2P);
