@@ -8,11 +8,14 @@
 // the compute phases and saturated during the store phases.  Here every WAVE is its own pipeline:
 //   * it owns one 32-row fragment of dY for the whole K extent: loaded once (two float4 per k-step and lane),
 //     split into bf16 hi/lo once, kept in registers (8*KS VGPRs);
-//   * the static operand Wd is pre-split once per step in MFMA B-fragment order (k_wfrag_build), so a column
-//     fragment is 2*KS lane-linear 16-byte loads straight from L2 - no LDS, no barriers, no conversion;
-//   * it walks a range of 32-column fragments, double-buffered in registers: the loads of fragment j+1 fly while
-//     fragment j is multiplied (3*KS MFMAs) and stored, so stores leave in a steady stream instead of bursts;
-//   * all waves of the launch are resident at once (2 per SIMD), no second round, no tail.
+//   * the static operand Wd is pre-split once per step in MFMA B-fragment order (k_wfrag_build); a 32-column
+//     fragment (16 KB at O = 128) is copied L2 -> LDS by the 4 waves of a workgroup together, no conversion, and read
+//     back lane-linearly (conflict-free).  (A first version let every wave fetch its own fragments from L2:
+//     146 MB per decoder launch, no faster than the tiled GEMM.)
+//   * the workgroup walks a range of column fragments, double-buffered: the loads of fragment j+1 fly while fragment
+//     j is multiplied (3*KS MFMAs) and stored, one barrier per fragment, so stores leave in a steady stream instead
+//     of bursts;
+//   * ~3 workgroups per CU are resident at once, no second round, no tail.
 #pragma once
 #include "gemm_bf16x3.h"
 
@@ -47,59 +50,109 @@ struct DgradP {
     long long R, PS;
     int O, ncols, Cp;       // ncols = G*Cp
     int ncf, parts, cf_per_part;
+    int dbg;                // -DMCRN_ABLATE builds only (MCRN_DEBUG bits): 1 = no stores, 2 = no MFMA, 4 = no B staging
 };
 
 template <int KS>
-__global__ __launch_bounds__(256, 2) void dgrad_stream_kernel(const DgradP p) {   // 2 workgroups per CU = 2 waves per SIMD: <= 256 VGPRs+AGPRs
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) void dgrad_stream_kernel(const DgradP p) {   // <= 3 waves per SIMD: keeps the compiler from spilling the staging registers to reach a higher occupancy
+    constexpr int FRAG = KS * 2 * 64;                                 // uint4 per column fragment (hi and lo, all k-steps)
+    constexpr int NLD = (FRAG + 255) / 256;                           // uint4 per thread to stage one fragment
+    constexpr int O = 16 * KS;
+    constexpr int AROW = O + 4;                                       // padded row (floats) of the A bounce buffer
+    constexpr int ABYTES = 4 * 32 * AROW * 4, BBYTES = 2 * FRAG * 16;
+    // one LDS region: first the four waves' A bounce buffers, then (after a barrier) the two B stages
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[ABYTES > BBYTES ? ABYTES : BBYTES];
+    uint4 (*sB)[FRAG] = reinterpret_cast<uint4 (*)[FRAG]>(smem_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kq = lane >> 5;
-    const long long task = (long long)blockIdx.x * 4 + wave;          // (row fragment, column part); the 4 waves of a
-    const int part = (int)(task % p.parts);                           // workgroup share the row fragment when parts % 4 == 0
-    const long long rf = task / p.parts;
-    if (rf * 32 >= p.R) return;
+    // workgroup = (group of 4 row fragments, column part); wave w owns row fragment 4*rg + w; the workgroup walks the
+    // column fragments of its part together so that every B fragment is fetched from L2 once per 128 rows
+    const int part = (int)(blockIdx.x % p.parts);
+    const long long rg = blockIdx.x / p.parts;
+    const long long rf = rg * 4 + wave;
+    const bool live = rf * 32 < p.R;                                  // whole wave beyond the last row: helps staging only
+#ifdef MCRN_ABLATE
+    const int dbg = p.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
 
-    // ---- A: this wave's 32 rows for the whole K extent, split once, resident
+    // ---- A: this wave's 32 rows for the whole K extent, split once, resident.  The 32 rows are ONE contiguous
+    // 128*O-byte block of dY: it is read with fully coalesced 16-byte loads and bounced through LDS into fragment
+    // order.  (Reading it directly in fragment order - 32 bytes per lane from 32 different rows - used a quarter of
+    // every 128-byte line it touched and alone cost 20 of the kernel's 25 us.)
     uint4 ah[KS], al[KS];
     {
-        const long long row = min(rf * 32 + l31, p.R - 1);            // clamped rows are never stored
-        const float* __restrict__ a = p.dY + row * p.O + 8 * kq;
+        float* __restrict__ sa = reinterpret_cast<float*>(smem_) + wave * 32 * AROW;
+        const long long base = rf * 32 * O;                           // first float of the block
+        const long long lim = p.R * O;                                // floats in dY
+#pragma unroll
+        for (int i = 0; i < O / 8; ++i) {                             // 32*O/4 float4 over 64 lanes
+            const int e = lane + 64 * i;                              // float4 index inside the block
+            long long src = base + 4LL * e;
+            if (src + 4 > lim) src = lim - 4;                         // rows beyond R: any valid address, never stored
+            if (src < 0) src = 0;
+            const float4 x = *reinterpret_cast<const float4*>(p.dY + src);
+            const int row = (4 * e) / O, k = (4 * e) % O;
+            *reinterpret_cast<float4*>(sa + row * AROW + k) = x;
+        }
+        // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float4 x = *reinterpret_cast<const float4*>(a + 16 * ks);
-            const float4 y = *reinterpret_cast<const float4*>(a + 16 * ks + 4);
+            const float4 x = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq);
+            const float4 y = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq + 4);
             const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
             split8(v, ah[ks], al[ks]);
         }
     }
+    __syncthreads();                                                  // the B stages reuse the bounce buffers
     const int j0 = part * p.cf_per_part;
     const int j1 = min(p.ncf, j0 + p.cf_per_part);
-    if (j0 >= j1) return;
+    if (j0 >= j1) return;                                             // uniform over the workgroup
     const long long r0 = rf * 32 + 4 * kq;
     const bool rows_in = rf * 32 + 32 <= p.R;                         // wave-uniform
 
-    uint4 b0h[KS], b0l[KS], b1h[KS], b1l[KS];
-    auto load_b = [&](int j, uint4 (&bh)[KS], uint4 (&bl)[KS]) {
-        const uint4* __restrict__ w = p.Wfrag + (long long)j * KS * 2 * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bh[ks] = w[(ks * 2 + 0) * 64];
-            bl[ks] = w[(ks * 2 + 1) * 64];
-        }
-    };
-    auto mma_store = [&](int j, const uint4 (&bh)[KS], const uint4 (&bl)[KS]) {
+    // staging registers as four scalars (NLD <= 4): as an array - lambda-captured or not - they were kept in scratch
+    uint4 s0 = make_uint4(0u, 0u, 0u, 0u), s1 = s0, s2 = s0, s3 = s0;
+    static_assert(NLD <= 4, "O <= 128");
+#define MCRN_DG_E(i) ((FRAG % 256 == 0 || tid + 256 * (i) < FRAG) ? tid + 256 * (i) : FRAG - 1)
+#define MCRN_DG_FETCH(J)                                                                       \
+    do {                                                                                       \
+        const uint4* __restrict__ w_ = p.Wfrag + (long long)(J) * FRAG;                        \
+        s0 = w_[MCRN_DG_E(0)];                                                                 \
+        if constexpr (NLD > 1) s1 = w_[MCRN_DG_E(1)];                                          \
+        if constexpr (NLD > 2) s2 = w_[MCRN_DG_E(2)];                                          \
+        if constexpr (NLD > 3) s3 = w_[MCRN_DG_E(3)];                                          \
+    } while (0)
+#define MCRN_DG_OK(i) (FRAG % 256 == 0 || tid + 256 * (i) < FRAG)
+#define MCRN_DG_PUBLISH(S)                                                                     \
+    do {                                                                                       \
+        if (MCRN_DG_OK(0)) sB[S][tid] = s0;                                                    \
+        if constexpr (NLD > 1) { if (MCRN_DG_OK(1)) sB[S][tid + 256] = s1; }                   \
+        if constexpr (NLD > 2) { if (MCRN_DG_OK(2)) sB[S][tid + 512] = s2; }                   \
+        if constexpr (NLD > 3) { if (MCRN_DG_OK(3)) sB[S][tid + 768] = s3; }                   \
+    } while (0)
+    MCRN_DG_FETCH(j0);
+    MCRN_DG_PUBLISH(0);
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+        const int s = (j - j0) & 1;
+        if (j + 1 < j1 && !(dbg & 4)) MCRN_DG_FETCH(j + 1);          // in flight during the MFMA chain and the stores
         f32x16 acc, acx;                                               // main product / the two cross products
 #pragma unroll
         for (int v = 0; v < 16; ++v) { acc[v] = 0.f; acx[v] = 0.f; }
+        if (!(dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]), xl = __builtin_bit_cast(bf16x8, al[ks]);
-            const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[ks]), yl = __builtin_bit_cast(bf16x8, bl[ks]);
+            const bf16x8 yh = __builtin_bit_cast(bf16x8, sB[s][(ks * 2 + 0) * 64 + lane]);
+            const bf16x8 yl = __builtin_bit_cast(bf16x8, sB[s][(ks * 2 + 1) * 64 + lane]);
             acx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acx, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
             acx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acx, 0, 0, 0);
         }
         const int n = 32 * j + l31;                                    // C/D layout: column = lane & 31
-        if (n < p.ncols) {
+        if (live && n < p.ncols && !(dbg & 1)) {
             const int g = n / p.Cp;
             float* __restrict__ c = p.dP + (long long)g * p.PS + (n - g * p.Cp) + r0 * p.Cp;
             int cp = p.Cp;
@@ -110,29 +163,26 @@ __global__ __launch_bounds__(256, 2) void dgrad_stream_kernel(const DgradP p) { 
                 if (rows_in || r0 + dr < p.R) c[dr * cp] = acc[v] + acx[v];
             }
         }
-    };
-    load_b(j0, b0h, b0l);
-    for (int j = j0; j < j1; j += 2) {
-        if (j + 1 < j1) load_b(j + 1, b1h, b1l);
-        mma_store(j, b0h, b0l);
-        if (j + 2 < j1) load_b(j + 2, b0h, b0l);
-        if (j + 1 < j1) mma_store(j + 1, b1h, b1l);
+        if (j + 1 < j1) MCRN_DG_PUBLISH(s ^ 1);                        // every wave left stage s^1 before the previous barrier
+        __syncthreads();
     }
+#undef MCRN_DG_FETCH
+#undef MCRN_DG_PUBLISH
+#undef MCRN_DG_E
+#undef MCRN_DG_OK
 }
 
 static inline hipError_t launch_dgrad_stream(DgradP p, hipStream_t st) {
     (void)hipGetLastError();
-    const long long nrf = (p.R + 31) / 32;
+    const long long nrg = (p.R + 127) / 128;                           // groups of 4 row fragments
     p.ncf = (p.ncols + 31) / 32;
-    // ~2048 resident waves (256 CUs x 4 SIMDs x 2): split the column fragments of a row fragment over `parts` waves
-    long long parts = 2048 / (nrf > 0 ? nrf : 1);
+    // ~3 workgroups per CU resident at once: split the column fragments of a row group over `parts` workgroups
+    long long parts = (768 + nrg - 1) / (nrg > 0 ? nrg : 1);
     if (parts < 1) parts = 1;
     if (parts > p.ncf) parts = p.ncf;
-    if (parts >= 4) parts &= ~3LL;                                     // the 4 waves of a workgroup then share their A rows
     p.cf_per_part = (int)((p.ncf + parts - 1) / parts);
     p.parts = (p.ncf + p.cf_per_part - 1) / p.cf_per_part;
-    const long long tasks = nrf * p.parts;
-    dim3 grid((unsigned)((tasks + 3) / 4));
+    dim3 grid((unsigned)(nrg * p.parts));
     switch (p.O / 16) {
         case 1: hipLaunchKernelGGL(dgrad_stream_kernel<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(dgrad_stream_kernel<2>, grid, dim3(256), 0, st, p); break;

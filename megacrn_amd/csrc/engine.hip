@@ -356,7 +356,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     if (imgd && g_precision == MCRN_BF16X3 && dgrad_stream_ok(O) && aligned16(dY)) {
         // d-grad, streaming form (dgrad_stream.h): imgd is the B-fragment image of Wd (built by wprep under the same test)
         DgradP q;
-        q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp;
+        q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp; q.dbg = g_debug;
         const double fl = 2.0 * (double)s.R * O * (double)(s.G * s.Cp);
         MCRN_PROF_WRAP(ROLE_DGRAD, launch_dgrad_stream(q, st), fl, 2.0 * (double)s.R * O * (double)(s.G * s.C));
     } else {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
