@@ -591,8 +591,20 @@ static int build_frags(const float* s1, const float* s2, long long ld, int N, ui
     ++g_launches; CK(launch_sfrag(s2, ld, N, 1, frag[3], st));
     return 0;
 }
+// scope guard: contractions issued while it lives use exact fp32 MFMA whatever the session precision
+struct ExactFp32 {
+    int saved;
+    ExactFp32() : saved(g_precision) { g_precision = MCRN_F32; }
+    ~ExactFp32() { g_precision = saved; }
+};
 static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
                         const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st) {
+    // The logits go through relu: a logit within the bf16x3 error (1e-5) of zero would get the wrong SIGN and flip
+    // its mask in the backward pass (one whole row of dWe1 / dWe2 off by 1e-2: tests/test_gpu_parity.py, H = 8,
+    // mem_num = 4).  These three GEMMs are tiny and run once per step, so they are evaluated in exact fp32, like
+    // the discrete top-2 choice of the memory head.
+    {
+    ExactFp32 exact_logits;
     for (int i = 0; i < 2; ++i) {   // E = We Mem
         GemmP p = gp();
         p.M = N; p.N = D; p.K = M;
@@ -609,6 +621,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.C[0] = o.L1; p.cm = plain(o.ldS); p.cn = plain(1);
         CKI(gemm(p, true, true, 0, ROLE_MISC, st));
     }
+    }   // exact_logits
     CKI(transpose(o.L2, o.ldS, o.L1, o.ldS, nullptr, 0, N, st));
     LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, N);
     LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, N);

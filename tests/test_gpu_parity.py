@@ -353,3 +353,37 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     G, _ = O.model_bwd(wts[0], cache, d_hatt=wts[1], d_query=wts[2])
     worst = {k: relerr(p.grad.cpu().numpy(), G[k]) for k, p in model.named_parameters()}
     assert max(worst.values()) < TOL, worst
+
+
+@pytest.mark.parametrize("N,B,H,D,T,why", [
+    (250, 320, 16, 8, 1, "8 row fragments (N > 224) with 96-column units: decoder B*Cp = 8960 columns = 140 64-column units > 128"),
+    (40, 5, 24, 8, 2, "streaming d-grad with 3 k-steps and its partial staging round (O = 48); O = 24 falls back to the tiled GEMM"),
+    (207, 3, 8, 8, 2, "streaming d-grad with a single k-step (O = 16); update O = 8 falls back"),
+])
+def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
+    """Shapes chosen to reach kernel variants the golden cases do not (see `why`): forward and every parameter
+    gradient of a train-mode step vs the float64 oracle."""
+    M, cheb_k = 4, 3
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=5)
+    rng = np.random.default_rng(9)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    teacher = [False, True][:T]
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000)
+    model = build(amd, P, m).train()
+    model._teacher_flags = lambda labels, bs: teacher
+    outs = model(dev(x), dev(ycov), dev(y), 0)
+    wts = [rng.standard_normal(o.shape) for o in outs[:3]]
+    sum((o * dev(w)).sum() for o, w in zip(outs[:3], wts)).backward()
+    torch.cuda.synchronize()
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    o64, cache = O.model_fwd(P64, x.astype(np.float64), ycov.astype(np.float64), y.astype(np.float64), teacher, cheb_k=cheb_k)
+    for a, b in zip(outs[:3], o64[:3]):
+        assert relerr(a.detach().cpu().numpy(), b) < TOL, why
+    G, _ = O.model_bwd(wts[0], cache, d_hatt=wts[1], d_query=wts[2])
+    worst = {k: relerr(p.grad.cpu().numpy(), G[k]) for k, p in model.named_parameters()}
+    assert max(worst.values()) < TOL, (why, worst)
