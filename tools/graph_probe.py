@@ -4,7 +4,10 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, megacrn_amd
+from megacrn_amd._lib import lib
 from megacrn_amd.trainer import FlatTrainer
+if len(sys.argv) > 1 and sys.argv[1] == "noside":      # single stream: the captured graph is one linear chain
+    lib.mcrn_set_side_stream(0)
 cfg = bench.CONFIGS["metrla"]
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
