@@ -894,6 +894,13 @@ static int memory_fwd_launch(const float* h, long long ldh, const float* Wq, con
 static int memory_bwd_rows_launch(const float* dval_rows, long long ldv, int c0, const float* dval_bnc,
                                   const float* dq_bnc, const float* att_rows, const float* Mem, int B, int N,
                                   int M, int D, float* dval_out, float* dsc, float* dq, hipStream_t st) {
+    if (M <= 64 && D <= 256 && (size_t)M * D * sizeof(float) <= 64 * 1024) {   // one wave per row
+        const long long R = (long long)N * B;
+        const int blocks = (int)std::min<long long>(cdiv(R, 4), 2048);
+        LAUNCH(k_memory_bwd_rows_w, dim3(blocks), dim3(256), (size_t)M * D * sizeof(float), st, dval_rows, ldv, c0, dval_bnc,
+               dq_bnc, att_rows, Mem, B, N, M, D, dval_out, dsc, dq);
+        return 0;
+    }
     const int nt = 64;
     size_t shm = ((size_t)M * D + (size_t)(D + M) * nt) * sizeof(float);
     if (shm > 160 * 1024) FAIL("memory head too large for LDS");
@@ -1565,7 +1572,7 @@ int mcrn_loss_fwd_bwd(int B, int T, int N, int od, int D, const float* output, c
         FAIL("loss: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long long nout = (long long)B * T * N * od, rows = (long long)B * N;
-    int nblk = cdiv(nout, 256 * 4);
+    int nblk = (int)std::max<long long>(cdiv(nout, 256 * 4), cdiv(rows, 4 * 4));   // ~4 rows per wave in the triplet part
     if (nblk > 1024) nblk = 1024;
     LAUNCH(k_loss_stage1, dim3(nblk), dim3(256), 0, st, output, labels, nout, query, pos, neg, rows, D, mean, stdv,
            lamb, lamb1, margin, scratch, d_query);

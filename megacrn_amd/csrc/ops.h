@@ -363,6 +363,71 @@ __global__ void k_memory_bwd_rows(const float* __restrict__ dval_rows, long long
     }
 }
 
+// Same, one WAVE per row (M <= 64, D <= 256): lanes over d for the two contractions with Mem (staged in LDS once per
+// workgroup), lanes over m for the softmax backward.  The thread-per-row kernel above ran 207 single-wave workgroups
+// with 2*M*D serial multiply-adds per thread: 94 us at METR-LA.
+__global__ __launch_bounds__(256) void k_memory_bwd_rows_w(const float* __restrict__ dval_rows, long long ldv, int c0,
+                                                           const float* __restrict__ dval_bnc, const float* __restrict__ dq_bnc,
+                                                           const float* __restrict__ att_rows, const float* __restrict__ Mem,
+                                                           int B, int N, int M, int D, float* __restrict__ dval_out,
+                                                           float* __restrict__ dsc_rows, float* __restrict__ dq_rows) {
+    extern __shared__ float sMem[];
+    for (int i = threadIdx.x; i < M * D; i += blockDim.x) sMem[i] = Mem[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const long long R = (long long)N * B;
+    for (long long r = (long long)blockIdx.x * wpb + wave; r < R; r += (long long)gridDim.x * wpb) {
+        const int n = (int)(r / B), b = (int)(r % B);
+        const long long o = ((long long)b * N + n) * D;
+        float dv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane + 64 * j;
+            float v = 0.f;
+            if (d < D) {
+                if (dval_rows) v += dval_rows[r * ldv + c0 + d];
+                if (dval_bnc) v += dval_bnc[o + d];
+                dval_out[r * D + d] = v;
+            }
+            dv[j] = v;
+        }
+        float da = 0.f;                                   // lane m holds datt[m] = sum_d dv[d] Mem[m][d]
+        for (int m = 0; m < M; ++m) {
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = lane + 64 * j;
+                if (d < D) part += dv[j] * sMem[m * D + d];
+            }
+            const float sm = wave_sum(part);
+            if (lane == m) da = sm;
+        }
+        const float att = lane < M ? att_rows[r * M + lane] : 0.f;
+        const float dot = wave_sum(da * att);
+        const float dsc = att * (da - dot);
+        if (lane < M) dsc_rows[r * M + lane] = dsc;
+        float dq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane + 64 * j;
+            dq[j] = (dq_bnc && d < D) ? dq_bnc[o + d] : 0.f;
+        }
+        for (int m = 0; m < M; ++m) {
+            const float w = __shfl(dsc, m, 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = lane + 64 * j;
+                if (d < D) dq[j] += w * sMem[m * D + d];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane + 64 * j;
+            if (d < D) dq_rows[r * D + d] = dq[j];
+        }
+    }
+}
+
 // dMem[ind[r][which]] += dsel[b,n,:]   (only when the caller did not detach pos/neg)
 __global__ void k_memory_scatter(float* __restrict__ dMem, const int* __restrict__ ind_rows, int which,
                                  const float* __restrict__ dsel_bnc, int B, int N, int D) {
@@ -622,20 +687,23 @@ __global__ void k_loss_stage1(const float* __restrict__ out, const float* __rest
         if (yt != 0.f) { cnt += 1.f; sab += fabsf(yp - yt); }
     }
     const float inv_rows = 1.f / (float)rows, inv_rd = 1.f / ((float)rows * (float)D);
-    for (long long r = g0; r < rows; r += gs) {
+    // triplet + MSE terms: one WAVE per (b, n) row, lanes over the D channels (coalesced; a thread per row walked its
+    // three D-vectors serially: 56 us).  Row sums are wave-uniform, so only lane 0 adds them to its partials.
+    const int lane = threadIdx.x & 63;
+    const long long nwave = gs >> 6;
+    for (long long r = g0 >> 6; r < rows; r += nwave) {
         const float* qr = q + r * D; const float* pr = pos + r * D; const float* nr = neg + r * D;
         float lp = 0.f, ln = 0.f, s2 = 0.f;
-        for (int d = 0; d < D; ++d) {
+        for (int d = lane; d < D; d += 64) {
             const float a = qr[d], dp = a - pr[d] + 1e-6f, dn = a - nr[d] + 1e-6f, e = a - pr[d];
             lp += dp * dp; ln += dn * dn; s2 += e * e;
         }
-        lp = sqrtf(lp); ln = sqrtf(ln);
+        lp = sqrtf(wave_sum(lp)); ln = sqrtf(wave_sum(ln)); s2 = wave_sum(s2);
         const float v = lp - ln + margin;
         const bool act = v > 0.f;
-        if (act) trip += v;
-        sq += s2;
+        if (lane == 0) { if (act) trip += v; sq += s2; }
         const float cp = act ? lamb * inv_rows / lp : 0.f, cn = act ? lamb * inv_rows / ln : 0.f;
-        for (int d = 0; d < D; ++d) {
+        for (int d = lane; d < D; d += 64) {
             const float a = qr[d];
             dq[r * D + d] = cp * (a - pr[d] + 1e-6f) - cn * (a - nr[d] + 1e-6f) + lamb1 * 2.f * inv_rd * (a - pr[d]);
         }
