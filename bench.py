@@ -79,8 +79,18 @@ def pmc_traffic(config_name, dtype, N):
     return round(tot / n) if n else None
 
 
-def cpu_baseline(cfg, sample_B, steps):
-    """The numpy oracle (a port of the reference CPU path) timed on this host, bounded sample."""
+def cpu_model_string():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sample_B, steps, nthr):
+    """The numpy oracle (a port of the reference CPU path) timed on this host, bounded sample, `nthr` BLAS threads."""
     from oracle import megacrn_oracle as O
     N, T, H = cfg["N"], cfg["T"], cfg["H"]
     P = O.init_params(N, rnn_units=H, mem_num=cfg["M"], mem_dim=cfg["D"], seed=0)
@@ -90,14 +100,30 @@ def cpu_baseline(cfg, sample_B, steps):
     y = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
     opt = O.Adam(P)
     from threadpoolctl import threadpool_limits
-    nthr = min(32, os.cpu_count() or 1)      # more BLAS threads than this only slows these small matrices
     with threadpool_limits(limits=nthr):
-        O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
+        if nthr > 1:
+            O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
         t = time.perf_counter()
         for s in range(steps):
             O.train_step(P, opt, x, yc, y, [s % 2 == 0] * T, SC_MEAN, SC_STD)
         dt = time.perf_counter() - t
-    return sample_B * steps / dt, dt, nthr
+    return sample_B * steps / dt, dt
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves, as children,
+    BEFORE this process touches the GPU (a process that initialised HIP must never re-exec), and pass their exit
+    code on.  One rank per GPU, rendezvous on 127.0.0.1, backend nccl (= RCCL over xGMI)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -107,9 +133,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="metrla", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU runs the config batch; strong: the config batch is split over the GPUs")
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"], help="default: per config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import megacrn_amd
     from megacrn_amd import dp
@@ -119,12 +150,15 @@ def main():
 
     rank, local_rank, world = dp.init_from_env("nccl")
     if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["B"]
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"strong scaling: batch {B} is not divisible by {world} GPUs")
+        B //= world
 
     torch.manual_seed(1234)            # identical init on every rank (also broadcast by the trainer)
     dp.seed_curriculum(1234)           # shared numpy stream: same teacher-forcing draws on all ranks
@@ -192,12 +226,18 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample (about 10-30 s of CPU work in total): B/4 samples on all useful cores, B/16 on ONE thread
+        # (the reference trainer pins one thread, model/traintest_MegaCRN.py:255-261)
+        nthr = min(32, os.cpu_count() or 1)      # more BLAS threads than this only slows these small matrices
         sample_B = max(1, B // 4)
-        v, secs, nthr = cpu_baseline(cfg, sample_B, 3)
+        v, secs = cpu_baseline(cfg, sample_B, 2, nthr)
+        s1 = max(1, B // 16)
+        v1, secs1 = cpu_baseline(cfg, s1, 1, 1)
         cpu = {"value": round(v, 3), "unit": "samples/s", "cores": nthr, "kind": "port",
-               "sample": f"oracle/megacrn_oracle.py (numpy, {nthr} BLAS threads of {os.cpu_count()} host cores) full "
-                         f"train step on {sample_B} of the {B} samples of the same {cfg['label']} workload, 3 timed "
-                         f"steps after 1 warm-up ({secs:.1f} s)"}
+               "value_1thread": round(v1, 3), "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
+               "sample": f"oracle/megacrn_oracle.py (numpy port of the reference CPU path) full train step of the same "
+                         f"{cfg['label']} workload: {sample_B} of the {B} samples, {nthr} BLAS threads, 2 timed steps "
+                         f"after 1 warm-up ({secs:.1f} s); value_1thread: {s1} samples, 1 thread, 1 step ({secs1:.1f} s)"}
 
     if rank == 0:
         gb = B * world
@@ -206,7 +246,8 @@ def main():
         out = {
             "metric": "training samples/sec (12-step seq2seq)" if cfg["T"] == 12 else "training samples/sec (6-step seq2seq)",
             "value": round(val, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
+            "backend": "rccl" if world > 1 else "single-process", "world_size": world,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} "
                                    f"mem={cfg['M']}x{cfg['D']} cheb_k=3, per-GPU batch {B}, full train step "

@@ -165,6 +165,21 @@ int mcrn_loss_fwd_bwd(int B, int T, int N, int output_dim, int D, const float* o
                       float lamb1, float margin, float* scratch, float* losses, float* d_output, float* d_query,
                       void* stream);
 
+/* ---- evaluation metrics of the trainer, one launch per batch, accumulated on device
+ *      (model/traintest_MegaCRN.py:63-93 with model/utils.py:126-160) ----
+ * Adds this batch's values to acc (device, >= 17 floats, zero before the first batch of an evaluation):
+ *   acc[0] += masked_mae + lamb*triplet + lamb1*mse (the evaluation loss, :66-72);
+ *   acc[1+3s+{0,1,2}] += masked {MAE, MAPE, MSE} of slice s: s = 0 the whole batch (:75-77), s = 1..nh the
+ *   single-step slices y[:, horizons[s-1]-1] (:79-88; horizons are 1-based step numbers, nh <= 3);
+ *   acc[13] += 1 (batches); acc[14..16] = this batch's {masked_mae, triplet, mse}.
+ * The epoch figures are acc[k]/acc[13] (RMSE = sqrt of the mean MSE, :89-93).  No host synchronisation.
+ * scratch: >= 64 + 18*1024 floats, zero-filled once by the caller before the first call (word 0 is an arrival
+ * counter that the kernel re-arms itself). */
+int mcrn_eval_metrics(int B, int T, int N, int output_dim, int D, const float* output, const float* labels,
+                      const float* query, const float* pos, const float* neg, float mean, float std, float lamb,
+                      float lamb1, float margin, const int* horizons, int nh, float* scratch, float* acc,
+                      void* stream);
+
 /* ---- test hook: C = alpha*op(A)*op(B) + beta*C on the library's MFMA GEMM ---- */
 /* A is (M,K) row-major if !transA else (K,M); B is (K,N) if !transB else (N,K); C (M,N). */
 int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B,

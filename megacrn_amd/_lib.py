@@ -23,7 +23,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
+    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_eval_metrics", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
 ]
 
 
@@ -101,6 +101,8 @@ def _load():
     lib.mcrn_flat_clip_adam.argtypes = [vp, vp, vp, vp, ll, f, f, f, f, i, f, f, vp, vp, vp]
     lib.mcrn_loss_fwd_bwd.restype = i
     lib.mcrn_loss_fwd_bwd.argtypes = [i] * 5 + [vp] * 5 + [f] * 5 + [vp] * 4 + [vp]
+    lib.mcrn_eval_metrics.restype = i
+    lib.mcrn_eval_metrics.argtypes = [i] * 5 + [vp] * 5 + [f] * 5 + [C.POINTER(C.c_int), i, vp, vp, vp]
     lib.mcrn_gemm_f32.restype = i
     lib.mcrn_gemm_f32.argtypes = [i, i, i, i, i, vp, vp, vp, f, f, i, vp, vp]
     lib.mcrn_prof_begin.restype = i

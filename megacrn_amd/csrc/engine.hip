@@ -210,6 +210,16 @@ static int side_join(hipStream_t st) {
     return 0;
 }
 
+// error paths: forget pending fork/join state (the caller's next call starts clean)
+static void side_reset() { g_side.any = false; g_side.pending[0] = g_side.pending[1] = false; }
+// The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
+// thread per process (the launch model of bench.py / megacrn_amd.train: one process per GPU).
+struct PrecisionScope {
+    int saved;
+    explicit PrecisionScope(int p) : saved(g_precision) { g_precision = p; }
+    ~PrecisionScope() { g_precision = saved; }
+};
+
 // ---- bump allocator over the caller's workspace -------------------------------------------
 struct Bump {
     char* base;
@@ -1235,7 +1245,11 @@ const char* mcrn_last_error(void) { return g_err; }
 int mcrn_version(void) { return 100; }
 int mcrn_last_launch_count(void) { return g_launches; }
 
-int mcrn_set_gemm_cfg(int cfg) { g_force_cfg = cfg; return 0; }
+int mcrn_set_gemm_cfg(int cfg) {
+    if (cfg < -1 || cfg >= NCFG) FAIL("gemm cfg %d outside -1..%d", cfg, NCFG - 1);
+    g_force_cfg = cfg;
+    return 0;
+}
 int mcrn_set_debug(int bits) { g_debug = bits; return 0; }
 #ifdef MCRN_TIMELINE
 // measurement-only builds: copy out the in-kernel phase stamps (prop_small.h)
@@ -1281,11 +1295,13 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
     float* dq = q; q += nbd;
     mcrn_params_t P = {pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], pp[9], pp[10], pp[11], pp[12], pp[13]};
     mcrn_grads_t G = {gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9], gg[10], gg[11], gg[12], gg[13]};
-    g_precision = d->precision;
+    PrecisionScope prec(d->precision);
     g_tuning = true;
     int rc = model_forward(d, &P, x, yc, nullptr, nullptr, (char*)ws, out, o4[0], o4[1], o4[2], o4[3], st);
     if (!rc) rc = model_backward(d, &P, nullptr, dout, nullptr, dq, nullptr, nullptr, (char*)ws, &G, st);
     g_tuning = false;
+    g_force_cfg = -1;                     // a failed trial launch may have left the tuning loop's value behind
+    if (rc) { (void)hipStreamSynchronize(st); side_reset(); }
     (void)hipStreamSynchronize(st);
     (void)hipFree(buf);
     return rc;
@@ -1341,8 +1357,10 @@ int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float
     if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small: %zu < %zu", ws_bytes, mcrn_model_workspace_bytes(d));
     if (teacher && !labels) for (int t = 0; t < d->T_out; ++t) if (teacher[t]) FAIL("teacher forcing requested without labels");
     g_launches = 0;
-    g_precision = d->precision;
-    return model_forward(d, p, x, ycov, labels, teacher, (char*)ws, output, h_att, query, pos, neg, (hipStream_t)stream);
+    PrecisionScope prec(d->precision);   // the session precision of the stand-alone ops is restored on return
+    const int rc = model_forward(d, p, x, ycov, labels, teacher, (char*)ws, output, h_att, query, pos, neg, (hipStream_t)stream);
+    if (rc) side_reset();
+    return rc;
 }
 
 int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher, const float* d_output,
@@ -1351,8 +1369,10 @@ int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int*
     CKI(check_dims(d));
     if (!p || !d_output || !ws || !grads) FAIL("mcrn_model_backward: NULL argument");
     if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small");
-    g_precision = d->precision;
-    return model_backward(d, p, teacher, d_output, d_hatt, d_query, d_pos, d_neg, (char*)ws, grads, (hipStream_t)stream);
+    PrecisionScope prec(d->precision);
+    const int rc = model_backward(d, p, teacher, d_output, d_hatt, d_query, d_pos, d_neg, (char*)ws, grads, (hipStream_t)stream);
+    if (rc) side_reset();
+    return rc;
 }
 
 // ---- supports -----------------------------------------------------------------------------------
@@ -1554,8 +1574,9 @@ int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, flo
     if (nblk > 1000) nblk = 1000;
     LAUNCH(k_sumsq_stage1, dim3(nblk), dim3(256), 0, st, (const float*)g, n, grad_scale, scratch);
     LAUNCH(k_sumsq_stage2, dim3(1), dim3(64), 0, st, (const float*)scratch, nblk, scratch + 1000);
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // bias corrections in double like torch (Python floats): 1 - 0.999f^step in fp32 loses ~6e-5 to cancellation
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     LAUNCH(k_clip_adam, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, max_norm,
            grad_scale, (const float*)(scratch + 1000));
     if (total_norm_out) CK(hipMemcpyAsync(total_norm_out, scratch + 1000, sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1580,6 +1601,29 @@ int mcrn_loss_fwd_bwd(int B, int T, int N, int od, int D, const float* output, c
            scratch + 4096);
     LAUNCH(k_loss_dout, dim3(cdiv(nout, 256)), dim3(256), 0, st, output, labels, nout, mean, stdv,
            (const float*)(scratch + 4096), d_output);
+    return 0;
+}
+
+// ---- evaluation metrics, one launch per batch (model/traintest_MegaCRN.py:63-93) -------------------
+int mcrn_eval_metrics(int B, int T, int N, int od, int D, const float* output, const float* labels,
+                      const float* query, const float* pos, const float* neg, float mean, float stdv, float lamb,
+                      float lamb1, float margin, const int* horizons, int nh, float* scratch, float* acc,
+                      void* stream) {
+    if (B < 1 || T < 1 || N < 1 || od < 1 || D < 1 || !output || !labels || !query || !pos || !neg || !scratch || !acc ||
+        nh < 0 || nh > 3 || (nh > 0 && !horizons))
+        FAIL("eval_metrics: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int h[3] = {-1, -1, -1};
+    for (int i = 0; i < nh; ++i) {
+        if (horizons[i] < 1 || horizons[i] > T) FAIL("eval_metrics: horizon %d outside 1..%d", horizons[i], T);
+        h[i] = horizons[i] - 1;
+    }
+    const long long nout = (long long)B * T * N * od, rows = (long long)B * N;
+    int nblk = (int)std::max<long long>(cdiv(nout, 256 * 4), cdiv(rows, 4 * 4));
+    if (nblk > 1024) nblk = 1024;
+    // scratch: [0] ticket (zero before the first call; the kernel re-arms it), [64 ..) per-block partials
+    LAUNCH(k_eval_metrics, dim3(nblk), dim3(256), 0, st, output, labels, nout, T, (long long)N * od, h[0], h[1], h[2], query,
+           pos, neg, rows, D, mean, stdv, lamb, lamb1, margin, scratch + 64, reinterpret_cast<unsigned*>(scratch), acc);
     return 0;
 }
 

@@ -767,7 +767,8 @@ __global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float*
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float tn = total_norm[0];
-    float coef = fminf(1.f, max_norm / (tn + 1e-6f));
+    const float c = max_norm / (tn + 1e-6f);
+    float coef = c > 1.f ? 1.f : c;        // torch.clamp(c, max=1): a NaN norm stays NaN like clip_grad_norm_ (fminf would drop it)
     float gi = g[i] * scale * coef;
     g[i] = gi;
     float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -776,6 +777,108 @@ __global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float*
     v[i] = vi;
     float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// evaluation metrics of the trainer, ONE launch per batch, accumulated on device, no host sync
+// (model/traintest_MegaCRN.py:63-93 with model/utils.py:126-160):
+//   per batch: loss = masked_mae + lamb*triplet + lamb1*mse ; masked MAE / MAPE / MSE over the whole batch and over
+//   the single-step slices y[:, t] for up to three horizons t (the trainer's 3 / 6 / 12) ; the epoch result is the
+//   mean over batches of these per-batch values (RMSE = sqrt of the mean MSE), so the kernel adds each batch's
+//   values to `acc` and counts batches:
+//     acc[0] = sum loss ; acc[1 + 3s + {0,1,2}] = sum of {mae, mape, mse} of slice s (0 = overall, 1..3 = horizons) ;
+//     acc[13] = number of batches.
+// masked_X(pred, true) = mean(X * mask / mean(mask)), NaN -> 0  ==  sum_{true != 0} X / count   (0 when count == 0).
+// Every block leaves 18 partial sums; the last block to arrive (agent-scope release / ticket / acquire, guide G16)
+// reduces them in a fixed order, so the result does not depend on scheduling.
+// ---------------------------------------------------------------------------------------------
+#define MCRN_EVAL_NQ 18
+__global__ __launch_bounds__(256) void k_eval_metrics(const float* __restrict__ out, const float* __restrict__ lab,
+                                                      long long nout, int T, long long inner /* N*od */, int h0, int h1,
+                                                      int h2, const float* __restrict__ q, const float* __restrict__ pos,
+                                                      const float* __restrict__ neg, long long rows, int D, float mean,
+                                                      float stdv, float lamb, float lamb1, float margin,
+                                                      float* __restrict__ part, unsigned* __restrict__ ticket,
+                                                      float* __restrict__ acc) {
+    __shared__ float sh[4][MCRN_EVAL_NQ];
+    __shared__ int s_last;
+    float a[MCRN_EVAL_NQ];
+#pragma unroll
+    for (int j = 0; j < MCRN_EVAL_NQ; ++j) a[j] = 0.f;
+    const long long gs = (long long)gridDim.x * blockDim.x, g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = g0; i < nout; i += gs) {
+        const float yt = inv_transform(lab[i], stdv, mean);
+        const float yp = inv_transform(out[i], stdv, mean);
+        if (yt != 0.f) {
+            const float d = yt - yp;
+            const float ab = fabsf(yp - yt), ape = fabsf(d / yt), sq = d * d;
+            const int t = (int)((i / inner) % T);
+            a[0] += 1.f; a[1] += ab; a[2] += ape; a[3] += sq;
+            if (t == h0) { a[4] += 1.f; a[5] += ab; a[6] += ape; a[7] += sq; }
+            if (t == h1) { a[8] += 1.f; a[9] += ab; a[10] += ape; a[11] += sq; }
+            if (t == h2) { a[12] += 1.f; a[13] += ab; a[14] += ape; a[15] += sq; }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long nwave = gs >> 6;
+    for (long long r = g0 >> 6; r < rows; r += nwave) {     // triplet + MSE terms: one wave per (b, n) row
+        const float* qr = q + r * D; const float* pr = pos + r * D; const float* nr = neg + r * D;
+        float lp = 0.f, ln = 0.f, s2 = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float x = qr[d], dp = x - pr[d] + 1e-6f, dn = x - nr[d] + 1e-6f, e = x - pr[d];
+            lp += dp * dp; ln += dn * dn; s2 += e * e;
+        }
+        lp = sqrtf(wave_sum(lp)); ln = sqrtf(wave_sum(ln)); s2 = wave_sum(s2);
+        const float v = lp - ln + margin;
+        if (lane == 0) { if (v > 0.f) a[16] += v; a[17] += s2; }
+    }
+#pragma unroll
+    for (int j = 0; j < MCRN_EVAL_NQ; ++j) a[j] = wave_sum(a[j]);
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < MCRN_EVAL_NQ; ++j) sh[w][j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < MCRN_EVAL_NQ)
+        part[(long long)blockIdx.x * MCRN_EVAL_NQ + threadIdx.x] =
+            (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    // publish: the writers are all in wave 0; release at agent scope, then take a ticket
+    if (w == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == gridDim.x - 1) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (w == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float r[MCRN_EVAL_NQ];
+#pragma unroll
+        for (int j = 0; j < MCRN_EVAL_NQ; ++j) r[j] = 0.f;
+        for (int b = lane; b < (int)gridDim.x; b += 64)
+#pragma unroll
+            for (int j = 0; j < MCRN_EVAL_NQ; ++j) r[j] += part[(long long)b * MCRN_EVAL_NQ + j];
+#pragma unroll
+        for (int j = 0; j < MCRN_EVAL_NQ; ++j) r[j] = wave_sum(r[j]);
+        if (lane == 0) {
+            const float l1 = r[0] > 0.f ? r[1] / r[0] : 0.f;
+            const float l2 = r[16] / (float)rows, l3 = r[17] / ((float)rows * (float)D);
+            acc[0] += l1 + lamb * l2 + lamb1 * l3;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float c = r[4 * s];
+                acc[1 + 3 * s + 0] += c > 0.f ? r[4 * s + 1] / c : 0.f;
+                acc[1 + 3 * s + 1] += c > 0.f ? r[4 * s + 2] / c : 0.f;
+                acc[1 + 3 * s + 2] += c > 0.f ? r[4 * s + 3] / c : 0.f;
+            }
+            acc[13] += 1.f;
+            acc[14] = l1; acc[15] = l2; acc[16] = l3;      // last batch's loss terms (tests)
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+    }
 }
 
 }  // namespace mcrn

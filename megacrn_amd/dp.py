@@ -39,7 +39,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 
 
 def shard_bounds(global_batch: int, rk: int, ws: int) -> tuple[int, int]:
-    """rank r owns the r-th block of consecutive samples (sizes differ by at most one)."""
+    """rank r owns the r-th block of consecutive samples (sizes differ by at most one).  The step averages per-rank
+    gradients with weight 1/world, so it equals the global-batch gradient only for EQUAL shards (and equal mask
+    fractions, model/utils.py:127-128); megacrn_amd.train requires batch_size % world == 0."""
     base, rem = divmod(global_batch, ws)
     lo = rk * base + min(rk, rem)
     return lo, lo + base + (1 if rk < rem else 0)
@@ -57,3 +59,45 @@ def seed_curriculum(seed: int) -> None:
     """The curriculum draw is one np.random.uniform() per decoder step for the whole batch
     (model/MegaCRN.py:189): every rank must consume the same stream, so all ranks use `seed`."""
     np.random.seed(seed)
+
+
+class FlatBucket:
+    """The step's single message: every parameter lives in ONE flat fp32 buffer (`flat_p`), every gradient in a
+    second one (`flat_g`), each tensor in a 64-float (256 B) aligned slice.  `nn.Parameter`s of the reference shapes
+    are re-pointed at views of `flat_p` (state_dict keeps working), the backward pass writes gradients straight into
+    the views of `flat_g`, `allreduce()` is the ONE collective of a step, and `grad_scale` (= 1/world) is applied by
+    the consumer of the bucket (the fused clip+Adam kernel).  Device-agnostic: the CPU tests drive exactly this class
+    over gloo, the GPU path over RCCL."""
+
+    def __init__(self, params, group=None):
+        self.params = list(params)
+        self.group = group
+        self.world = world_size(group)
+        if not self.params:
+            raise ValueError("FlatBucket: no parameters")
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.offsets, o = [], 0
+        for n in self.sizes:
+            self.offsets.append(o)
+            o += (n + 63) // 64 * 64
+        self.n = o
+        self.flat_p = torch.zeros(o, device=dev)
+        self.flat_g = torch.zeros(o, device=dev)
+        self.grad_views = []
+        for p, off, n in zip(self.params, self.offsets, self.sizes):
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatBucket: parameters must be fp32 tensors on one device")
+            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            self.grad_views.append(self.flat_g[off:off + n].view(p.shape))
+        if self.world > 1:
+            broadcast_flat(self.flat_p, group)                 # identical weights on every rank
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def allreduce(self) -> None:
+        if self.world > 1:
+            allreduce_flat(self.flat_g, self.group)

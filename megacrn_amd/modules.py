@@ -409,6 +409,23 @@ class MegaCRN(nn.Module):
             flags.append(f)
         return flags
 
+    def _check_inputs(self, x, y_cov, labels):
+        """The fused C entry point takes raw pointers: reject here what the reference rejects with a shape
+        error in torch.cat / torch.stack (model/MegaCRN.py:67,106,185,192)."""
+        if x.dim() != 4 or x.shape[2] != self.num_nodes or x.shape[3] != self.input_dim:
+            raise ValueError(f"x must be (B, T_in, {self.num_nodes}, {self.input_dim}); got {tuple(x.shape)}")
+        B = x.shape[0]
+        want_c = (B, self.horizon, self.num_nodes, self.ycov_dim)
+        if y_cov is None or tuple(y_cov.shape[:3]) != want_c[:3] or y_cov.shape[3] < self.ycov_dim:
+            raise ValueError(f"y_cov must be {want_c}; got {None if y_cov is None else tuple(y_cov.shape)}")
+        if y_cov.shape[3] != self.ycov_dim:
+            raise ValueError(f"y_cov must be {want_c}; got {tuple(y_cov.shape)}")
+        if labels is not None and tuple(labels.shape) != (B, self.horizon, self.num_nodes, self.output_dim):
+            raise ValueError(f"labels must be {(B, self.horizon, self.num_nodes, self.output_dim)}; got {tuple(labels.shape)}")
+        for name, t in (("y_cov", y_cov), ("labels", labels)):
+            if t is not None and t.device != x.device:
+                raise ValueError(f"{name} lives on {t.device}, x on {x.device}")
+
     def _fused_params(self):
         e, dcd = self.encoder.dcrnn_cells[0], self.decoder.dcrnn_cells[0]
         return (self.memory['Memory'], self.memory['Wq'], self.memory['We1'], self.memory['We2'],
@@ -424,7 +441,7 @@ class MegaCRN(nn.Module):
                 raise ValueError("curriculum learning needs labels")
             d = Dims(x.shape[0], self.num_nodes, x.shape[1], self.horizon, self.input_dim, self.output_dim,
                      self.ycov_dim, self.rnn_units, self.mem_num, self.mem_dim, self.cheb_k, self.precision)
-            assert x.shape[2] == self.num_nodes and x.shape[3] == self.input_dim
+            self._check_inputs(x, y_cov, labels)
             return _ModelFn.apply(d, teacher, x, y_cov, labels, *self._fused_params())
         return self._forward_composed(x, y_cov, labels, batches_seen)
 

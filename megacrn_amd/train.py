@@ -15,7 +15,9 @@ Same flags and defaults (``:158-188``), same semantics:
   * evaluate: masked MAE / MAPE / RMSE overall and at horizons 3 / 6 / 12 as means of per-batch values
     (``:50-99``).
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N -m megacrn_amd.train ...``; every rank
-takes its block of each batch, one all-reduce per step.  ``--synthetic`` generates METR-LA-shaped windows when the
+takes its (equal) block of each batch, one all-reduce per step; rank 0's validation figures drive checkpointing and
+early stopping on every rank.  Inputs travel through a pinned, double-buffered copy stream (``Prefetcher``), the
+evaluation figures are accumulated on the device by one launch per batch (``DeviceMetrics``).  ``--synthetic`` generates METR-LA-shaped windows when the
 datasets are absent (they are not shipped with the reference either).
 """
 from __future__ import annotations
@@ -155,45 +157,136 @@ def load_data(args):
     return sets
 
 
-def prepare_x_y(x, y, args, device, lo=None, hi=None):
-    """(:33-48) channel split + float32 + H2D; optional [lo,hi) = this rank's shard of the batch."""
+def split_x_y(x, y, args, lo=None, hi=None):
+    """Host half of prepare_x_y (:33-48): channel split, float32; optional [lo,hi) = this rank's shard."""
     if lo is not None:
         x, y = x[lo:hi], y[lo:hi]
-    x0 = torch.from_numpy(np.ascontiguousarray(x[..., :args.input_dim])).float()
-    y0 = torch.from_numpy(np.ascontiguousarray(y[..., :args.output_dim])).float()
-    y1 = torch.from_numpy(np.ascontiguousarray(y[..., args.output_dim:])).float()
-    return x0.to(device), y0.to(device), y1.to(device)
+    x0 = np.ascontiguousarray(x[..., :args.input_dim], dtype=np.float32)
+    y0 = np.ascontiguousarray(y[..., :args.output_dim], dtype=np.float32)
+    y1 = np.ascontiguousarray(y[..., args.output_dim:], dtype=np.float32)
+    return x0, y0, y1
 
 
-def evaluate(model, loader, scaler, args, device, log=None, mode='val'):
-    horizons = [h for h in (3, 6, 12) if h <= args.horizon]
+def prepare_x_y(x, y, args, device, lo=None, hi=None):
+    """(:33-48) channel split + float32 + synchronous H2D -> x, y, y_cov."""
+    return tuple(torch.from_numpy(a).to(device) for a in split_x_y(x, y, args, lo, hi))
+
+
+class Prefetcher:
+    """Pinned, double-buffered host-to-device input pipeline (the H2D boundary of :116, once per batch).
+
+    While the GPU works on batch i, the host thread splits batch i+1 into pinned staging buffers and a
+    dedicated copy stream moves it into the other device slot; the compute stream only waits on the copy's
+    event.  A slot is refilled only after the compute stream has passed the event recorded when its previous
+    occupant was consumed (`release`), so nothing is overwritten while kernels still read it.  Order and contents
+    are exactly those of iterating the loader and calling prepare_x_y on every batch."""
+
+    def __init__(self, iterator, args, device, shard=None, depth=2):
+        self.it, self.args, self.device, self.shard, self.depth = iterator, args, device, shard, depth
+        self.copy = torch.cuda.Stream(device=device)
+        self.slots = [None] * depth          # per slot: (pinned triple, device triple)
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.free = [None] * depth           # event after which the slot's device buffers may be overwritten
+        self.queue = []
+        self.n = 0
+        self._fill()
+
+    def _fill(self):
+        while len(self.queue) < self.depth:
+            try:
+                x, y = next(self.it)
+            except StopIteration:
+                return
+            lo, hi = self.shard(len(x)) if self.shard else (None, None)
+            host = split_x_y(x, y, self.args, lo, hi)
+            k = self.n % self.depth
+            self.n += 1
+            if self.slots[k] is None or any(p.shape != h.shape for p, h in zip(self.slots[k][0], host)):
+                pin = tuple(torch.empty(h.shape, dtype=torch.float32).pin_memory() for h in host)
+                dev = tuple(torch.empty(h.shape, dtype=torch.float32, device=self.device) for h in host)
+                self.slots[k] = (pin, dev)
+            pin, dev = self.slots[k]
+            if self.free[k] is not None:
+                self.ready[k].synchronize()                    # the earlier copy OUT of this pinned staging is done
+            with torch.cuda.stream(self.copy):
+                if self.free[k] is not None:
+                    self.copy.wait_event(self.free[k])         # consumer kernels of the old occupant are done
+                for p, h, d in zip(pin, host, dev):
+                    p.copy_(torch.from_numpy(h))
+                    d.copy_(p, non_blocking=True)
+                self.ready[k].record(self.copy)
+            self.queue.append(k)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.queue:
+            raise StopIteration
+        k = self.queue.pop(0)
+        torch.cuda.current_stream(self.device).wait_event(self.ready[k])
+        self._last = k
+        return self.slots[k][1]
+
+    def release(self):
+        """Call after the kernels that read the batch returned by the last __next__ have been enqueued."""
+        k = self._last
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.free[k] = ev
+        self._fill()
+
+
+class DeviceMetrics:
+    """Accumulates the evaluation figures of :63-93 on the device: one HIP launch per batch
+    (`mcrn_eval_metrics`), no `.item()`; `result()` is the single synchronisation of an evaluation."""
+
+    def __init__(self, args, scaler, device):
+        from ._lib import lib, check
+        import ctypes as C
+        self.lib, self.check, self.C = lib, check, C
+        self.hz = [h for h in (3, 6, 12) if h <= args.horizon]
+        self.harr = (C.c_int * 3)(*(self.hz + [0] * (3 - len(self.hz))))
+        self.mean, self.std, self.lamb, self.lamb1 = float(scaler.mean), float(scaler.std), args.lamb, args.lamb1
+        self.scratch = torch.zeros(64 + 18 * 1024, device=device)
+        self.acc = torch.zeros(17, device=device)
+
+    def reset(self):
+        self.acc.zero_()
+
+    def add(self, output, labels, query, pos, neg):
+        B, T, N, od = output.shape
+        self.check(self.lib.mcrn_eval_metrics(B, T, N, od, query.shape[-1], output.data_ptr(), labels.data_ptr(),
+                                              query.data_ptr(), pos.data_ptr(), neg.data_ptr(), self.mean, self.std,
+                                              self.lamb, self.lamb1, 1.0, self.harr, len(self.hz),
+                                              self.scratch.data_ptr(), self.acc.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "mcrn_eval_metrics")
+
+    def result(self):
+        a = self.acc.cpu().numpy().astype(np.float64)        # the one sync
+        n = max(a[13], 1.0)
+        res = {'loss': a[0] / n, 'mae': a[1] / n, 'mape': a[2] / n, 'rmse': float(np.sqrt(a[3] / n))}
+        for i, h in enumerate(self.hz):
+            res[f'mae_{h}'], res[f'mape_{h}'] = a[4 + 3 * i] / n, a[5 + 3 * i] / n
+            res[f'rmse_{h}'] = float(np.sqrt(a[6 + 3 * i] / n))
+        return {k: float(v) for k, v in res.items()}
+
+
+def evaluate(model, loader, scaler, args, device, log=None, mode='val', metrics=None):
+    """(:50-99) eval-mode forward over the loader; every figure is accumulated on the device."""
+    metrics = metrics or DeviceMetrics(args, scaler, device)
+    metrics.reset()
     with torch.no_grad():
         model.eval()
-        losses, maes, mapes, mses = [], [], [], []
-        per_h = {h: ([], [], []) for h in horizons}
-        triplet, mse = torch.nn.TripletMarginLoss(margin=1.0), torch.nn.MSELoss()
-        for x, y in loader.get_iterator():
-            x, y, ycov = prepare_x_y(x, y, args, device)
+        pf = Prefetcher(loader.get_iterator(), args, device)
+        for x, y, ycov in pf:
             output, h_att, query, pos, neg = model(x, ycov)
-            y_pred, y_true = scaler.inverse_transform(output), scaler.inverse_transform(y)
-            loss = masked_mae_loss(y_pred, y_true) + args.lamb * triplet(query, pos, neg) + args.lamb1 * mse(query, pos)
-            losses.append(loss.item())
-            maes.append(masked_mae_loss(y_pred, y_true).item())
-            mapes.append(masked_mape_loss(y_pred, y_true).item())
-            mses.append(masked_mse_loss(y_pred, y_true).item())
-            for h in horizons:
-                p, t = y_pred[:, h - 1:h], y_true[:, h - 1:h]
-                per_h[h][0].append(masked_mae_loss(p, t).item())
-                per_h[h][1].append(masked_mape_loss(p, t).item())
-                per_h[h][2].append(masked_mse_loss(p, t).item())
-    res = {'loss': float(np.mean(losses)), 'mae': float(np.mean(maes)), 'mape': float(np.mean(mapes)),
-           'rmse': float(np.sqrt(np.mean(mses)))}
-    for h in horizons:
-        res[f'mae_{h}'], res[f'mape_{h}'] = float(np.mean(per_h[h][0])), float(np.mean(per_h[h][1]))
-        res[f'rmse_{h}'] = float(np.sqrt(np.mean(per_h[h][2])))
+            metrics.add(output, y, query, pos, neg)
+            pf.release()
+    res = metrics.result()
     if log and mode == 'test':
         log.info('Horizon overall: mae: {:.4f}, mape: {:.4f}, rmse: {:.4f}'.format(res['mae'], res['mape'], res['rmse']))
-        for h in horizons:
+        for h in metrics.hz:
             log.info('Horizon {}mins: mae: {:.4f}, mape: {:.4f}, rmse: {:.4f}'.format(
                 5 * h, res[f'mae_{h}'], res[f'mape_{h}'], res[f'rmse_{h}']))
     return res
@@ -202,12 +295,16 @@ def evaluate(model, loader, scaler, args, device, log=None, mode='val'):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     import megacrn_amd
+    import torch.distributed as dist
     from megacrn_amd import dp
     from megacrn_amd.trainer import FlatTrainer
 
     rank, local_rank, world = dp.init_from_env()
     if args.dataset == 'PEMSBAY' and args.synthetic == 0:
         args.num_nodes = 325
+    if args.batch_size % world:
+        # equal shards: the step averages per-rank gradients with weight 1/world (multi-GPU semantics)
+        raise ValueError(f'--batch_size {args.batch_size} must be divisible by the number of ranks ({world})')
     device = torch.device('cuda', local_rank if world > 1 else args.gpu)
     torch.cuda.set_device(device)
     log = logging.getLogger('megacrn_amd.train')
@@ -238,28 +335,45 @@ def main(argv=None):
     model = get_model()
     tr = FlatTrainer(model, lr=args.lr, eps=args.epsilon, max_grad_norm=args.max_grad_norm, lamb=args.lamb,
                      lamb1=args.lamb1, scaler_mean=float(scaler.mean), scaler_std=float(scaler.std))
-    path = os.path.join(args.save_dir, f'{args.dataset}_MegaCRN_{time.strftime("%Y%m%d%H%M%S")}')
+    metrics = DeviceMetrics(args, scaler, device)
+    # one run directory for the whole job: rank 0 names it, everybody else is told
+    stamp = [time.strftime("%Y%m%d%H%M%S")]
+    if world > 1:
+        dist.broadcast_object_list(stamp, src=0)
+    path = os.path.join(args.save_dir, f'{args.dataset}_MegaCRN_{stamp[0]}')
     if rank == 0:
         os.makedirs(path, exist_ok=True)
     modelpt_path = os.path.join(path, 'MegaCRN.pt')
     milestones = sorted(args.steps)
     min_val, wait, history = float('inf'), 0, []
+    shard = (lambda n: dp.shard_bounds(n, rank, world)) if world > 1 else None
     for epoch in range(args.epochs):
         t0 = time.time()
         model.train()
         losses = []
-        for bi, (x, y) in enumerate(loaders['train'].get_iterator()):
-            lo, hi = dp.shard_bounds(len(x), rank, world)
-            xb, yb, ycov = prepare_x_y(x, y, args, device, lo, hi)
+        pf = Prefetcher(loaders['train'].get_iterator(), args, device, shard)
+        for bi, (xb, yb, ycov) in enumerate(pf):
             losses.append(tr.train_step(xb, ycov, yb))
+            pf.release()
             if args.max_batches and bi + 1 >= args.max_batches:
                 break
-        train_loss = float(torch.stack(losses).mean().item())        # one sync per epoch, not per step
+        tl = torch.stack(losses).mean()                               # one sync per epoch, not per step
+        if world > 1:                                                 # the logged loss covers every rank's shard
+            dist.all_reduce(tl)
+            tl /= world
+        train_loss = float(tl.item())
         tr.lr = args.lr * args.lr_decay_ratio ** sum(1 for m in milestones if epoch + 1 >= m)   # MultiStepLR (:132)
-        val = evaluate(model, loaders['val'], scaler, args, device)
+        # Every rank evaluates the full val / test sets (replicated weights), but ranks may autotune different GEMM
+        # tiles and differ in the last bits: rank 0's figures decide checkpoint and early stop for everybody, so
+        # all ranks leave the loop in the same epoch (no rank is left alone inside an all-reduce).
+        val = evaluate(model, loaders['val'], scaler, args, device, metrics=metrics)
+        test = evaluate(model, loaders['test'], scaler, args, device, log, 'test', metrics=metrics)
+        if world > 1:
+            dec = torch.tensor([val['loss'], test['mae']], device=device, dtype=torch.float64)
+            dist.broadcast(dec, src=0)
+            val['loss'], test['mae'] = float(dec[0].item()), float(dec[1].item())
         log.info('Epoch [{}/{}] ({}) train_loss: {:.4f}, val_loss: {:.4f}, lr: {:.6f}, {:.1f}s'.format(
             epoch + 1, args.epochs, tr.batches_seen, train_loss, val['loss'], tr.lr, time.time() - t0))
-        test = evaluate(model, loaders['test'], scaler, args, device, log, 'test')
         history.append((train_loss, val['loss'], test['mae']))
         if val['loss'] < min_val:
             wait, min_val = 0, val['loss']
@@ -271,10 +385,12 @@ def main(argv=None):
                 log.info('Early stopping at epoch: %d' % epoch)
                 break
     log.info('=' * 35 + 'Best model performance' + '=' * 35)
+    if world > 1:
+        dist.barrier()                     # rank 0's last checkpoint write is complete before anyone loads it
     if os.path.exists(modelpt_path):
         best = get_model()
         best.load_state_dict(torch.load(modelpt_path))
-        evaluate(best, loaders['test'], scaler, args, device, log, 'test')
+        evaluate(best, loaders['test'], scaler, args, device, log, 'test', metrics=metrics)
     return history
 
 

@@ -42,29 +42,16 @@ class FlatTrainer:
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatTrainer needs the model on a HIP device (no CPU fallback)")
-        sizes = [p.numel() for p in params]
-        # 64-float (256 B) aligned slices so every tensor keeps the alignment torch would give it
-        offs, o = [], 0
-        for n in sizes:
-            offs.append(o)
-            o += (n + 63) // 64 * 64
-        self.n = o
-        self.flat_p = torch.zeros(o, device=dev)
-        self.flat_g = torch.zeros(o, device=dev)
-        self.m = torch.zeros(o, device=dev)
-        self.v = torch.zeros(o, device=dev)
+        self.bucket = dp.FlatBucket(params, process_group)     # flat parameter / gradient buffers + the collective
+        self.n, self.flat_p, self.flat_g = self.bucket.n, self.bucket.flat_p, self.bucket.flat_g
+        self._gviews = self.bucket.grad_views
+        self.m = torch.zeros(self.n, device=dev)
+        self.v = torch.zeros(self.n, device=dev)
         self.scratch = torch.zeros(2048, device=dev)
         self.total_norm = torch.zeros(1, device=dev)
         self.loss_scratch = torch.zeros(4104, device=dev)
         self.losses = torch.zeros(4, device=dev)
-        self._gviews = []
-        for p, off, n in zip(params, offs, sizes):
-            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
-            p.data = self.flat_p[off:off + n].view(p.shape)
-            self._gviews.append(self.flat_g[off:off + n].view(p.shape))
         self.params = params
-        if self.world > 1:
-            dp.broadcast_flat(self.flat_p, process_group)      # identical weights on every rank
         self.step_count = 0
         self.batches_seen = 0
         self._ws = None
@@ -102,9 +89,36 @@ class FlatTrainer:
         loss3 = self.mse(query, pos)
         return loss1 + self.lamb * loss2 + self.lamb1 * loss3
 
+    def _check_inputs(self, x, ycov, labels):
+        """The C ABI takes raw pointers: everything the reference would reject with a shape error in
+        torch.cat / torch.stack (model/MegaCRN.py:42,185,192) is rejected here before any pointer is passed."""
+        m = self.model
+        dev = self.flat_p.device
+        if x.dim() != 4:
+            raise ValueError(f"x must be (B, T_in, N, input_dim); got {tuple(x.shape)}")
+        B, T_in = x.shape[0], x.shape[1]
+        want = {"x": (B, T_in, m.num_nodes, m.input_dim),
+                "y_cov": (B, m.horizon, m.num_nodes, m.ycov_dim),
+                "labels": (B, m.horizon, m.num_nodes, m.output_dim)}
+        out = []
+        for name, t in (("x", x), ("y_cov", ycov), ("labels", labels)):
+            if not isinstance(t, torch.Tensor):
+                raise ValueError(f"{name} must be a tensor")
+            if not t.is_cuda:
+                raise RuntimeError(f"{name}: megacrn_amd runs on MI355X only (got a {t.device} tensor); no CPU fallback")
+            if t.device != dev:
+                raise ValueError(f"{name} lives on {t.device}, the model on {dev}")
+            if t.dtype != torch.float32:
+                raise TypeError(f"{name}: megacrn_amd computes in fp32; got {t.dtype}")
+            if tuple(t.shape) != want[name]:
+                raise ValueError(f"{name} must have shape {want[name]}; got {tuple(t.shape)}")
+            out.append(t.contiguous())
+        return out
+
     def train_step(self, x, ycov, labels):
         """One optimizer step; returns the (device) loss tensor without synchronising."""
         m = self.model
+        x, ycov, labels = self._check_inputs(x, ycov, labels)
         self._prepare(x)
         st = torch.cuda.current_stream().cuda_stream
         teacher = m._teacher_flags(labels, self.batches_seen)
@@ -131,12 +145,11 @@ class FlatTrainer:
             d_out, d_q = torch.autograd.grad(loss, [out_l, q_l])
         check(lib.mcrn_model_backward(C.byref(self.d), C.byref(ps), tarr, d_out.data_ptr(), None, d_q.data_ptr(),
                                       None, None, self._ws.data_ptr(), nb, C.byref(gs), st), "mcrn_model_backward")
-        if self.world > 1:
-            dp.allreduce_flat(self.flat_g, self.group)       # the single collective of the step
+        self.bucket.allreduce()                              # the single collective of the step (no-op at world 1)
         self.step_count += 1
         check(lib.mcrn_flat_clip_adam(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(),
                                       self.v.data_ptr(), self.n, self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.step_count, self.max_grad_norm, 1.0 / self.world,
+                                      self.step_count, self.max_grad_norm, self.bucket.grad_scale,
                                       self.scratch.data_ptr(), self.total_norm.data_ptr(), st), "mcrn_flat_clip_adam")
         self.batches_seen += 1
         return loss.detach().clone() if self.fused_loss else loss.detach()

@@ -432,6 +432,58 @@ def loss_fwd_bwd(outs, labels, scaler_mean, scaler_std, lamb=0.01, lamb1=0.01):
     return (loss, l1, l2, l3), d_output, d_query
 
 
+# --------------------------------------------------------------------------
+# evaluation metrics  (model/utils.py:126-160, model/traintest_MegaCRN.py:63-93)
+# --------------------------------------------------------------------------
+
+
+def _masked(y_pred, y_true, fn):
+    """The masked_* family of model/utils.py: mask = (true != 0) / mean(mask), NaN -> 0, mean."""
+    mask = (y_true != 0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mask = mask / mask.mean()
+        loss = fn(y_pred, y_true) * mask
+    loss = np.where(loss != loss, 0, loss)
+    return float(loss.mean())
+
+
+def masked_mae(y_pred, y_true):
+    return _masked(y_pred, y_true, lambda p, t: np.abs(p - t))                 # :126-133
+
+
+def masked_mape(y_pred, y_true):
+    return _masked(y_pred, y_true, lambda p, t: np.abs((t - p) / t))           # :135-142
+
+
+def masked_mse(y_pred, y_true):
+    return _masked(y_pred, y_true, lambda p, t: (t - p) ** 2)                  # :153-160
+
+
+def eval_batch(outs, labels, scaler_mean, scaler_std, lamb=0.01, lamb1=0.01, horizons=(3, 6, 12)):
+    """One iteration of evaluate()'s loop (model/traintest_MegaCRN.py:61-88): returns
+    [loss, loss1, loss2, loss3, (mae, mape, mse) for the whole batch and for each single-step slice]."""
+    output, _hatt, query, pos, neg = outs
+    y_pred = (output * np.float32(scaler_std) + np.float32(scaler_mean)).astype(np.float32)
+    y_true = (labels * np.float32(scaler_std) + np.float32(scaler_mean)).astype(np.float32)
+    l1 = masked_mae(y_pred, y_true)
+    l2 = float(triplet_fwd_bwd(query, pos, neg)[0])
+    l3 = float(mse_fwd_bwd(query, pos)[0])
+    row = [l1 + lamb * l2 + lamb1 * l3, l1, l2, l3]
+    for sl in [slice(None)] + [slice(h - 1, h) for h in horizons if h <= y_true.shape[1]]:
+        row += [masked_mae(y_pred[:, sl], y_true[:, sl]), masked_mape(y_pred[:, sl], y_true[:, sl]),
+                masked_mse(y_pred[:, sl], y_true[:, sl])]
+    return row
+
+
+def eval_epoch(rows):
+    """:89-93: means of the per-batch values; RMSE = sqrt of the mean batch MSE."""
+    a = np.asarray(rows, np.float64).mean(0)
+    res = [a[0]]
+    for s in range((a.size - 4) // 3):
+        res += [a[4 + 3 * s], a[5 + 3 * s], float(np.sqrt(a[6 + 3 * s]))]
+    return res            # [mean loss, (mae, mape, rmse) x slices]
+
+
 def clip_grad_norm(G, max_norm=5.0):
     """torch.nn.utils.clip_grad_norm_ (:129): returns total norm, scales in place."""
     tot = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in G.values()))

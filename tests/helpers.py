@@ -31,3 +31,18 @@ def proto_mismatch_frac(got, want):
     want = np.asarray(want, np.float64).reshape(-1, want.shape[-1])
     bad = np.abs(got - want).max(axis=1) > 1e-6 * max(np.abs(want).max(), 1e-30)
     return float(bad.mean())
+
+
+def relerr_rows(a, b, floor=1e-3):
+    """Per-row normalised error of a 2-D gradient: max_r ( max|a_r - b_r| / max(max|b_r|, floor * max|b|) ).
+    `relerr` is relative to the whole tensor's largest entry, so a small-magnitude block (one row of dWe1, one
+    input-channel block of an AGCN weight) could be far off and pass; here every row is held to its own scale,
+    with rows below `floor` of the global scale normalised by that floor (their absolute error still counts)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.ndim == 1:
+        a, b = a[None], b[None]
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    g = max(np.abs(b).max(), 1e-30)
+    den = np.maximum(np.abs(b).max(axis=1), floor * g)
+    return float((np.abs(a - b).max(axis=1) / den).max())

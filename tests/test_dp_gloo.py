@@ -114,3 +114,66 @@ def test_equal_mask_fraction_makes_dp_exact():
     parts = [_shard_grad(P, rec2, m, i, i + 1, teacher)[0] for i in range(2)]
     mean = sum(_flat(g, keys) for g in parts) / 2
     assert relerr(mean, _flat(full, keys)) < 1e-10
+
+
+def _bucket_worker(rank, world, port, q):
+    """Drives the PRODUCT bucket code (megacrn_amd.dp.FlatBucket, the class FlatTrainer steps through):
+    flatten -> broadcast -> gradients written into the views -> ONE all-reduce -> grad_scale."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import megacrn_amd
+    from megacrn_amd import dp
+    from megacrn_amd._lib import PARAM_KEYS
+    dp.init_from_env("gloo")
+    rec, P, m = load_case("tiny", "f32")
+    model = megacrn_amd.MegaCRN(num_nodes=m["N"], input_dim=1, output_dim=1, horizon=m["T_out"], rnn_units=m["H"],
+                                mem_num=m["M"], mem_dim=m["D"])
+    model.load_state_dict({k: torch.from_numpy(v + np.float32(rank)) for k, v in P.items()})   # ranks start DIFFERENT
+    bucket = dp.FlatBucket(model._fused_params())
+    after_bcast = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    dp.seed_curriculum(99)
+    teacher = O.curriculum_flags(m["T_out"], True, True, 15200, m["cl_decay"])
+    B = 2                                                     # global batch of two samples, one per rank
+    lo, hi = dp.shard_bounds(B, rank, world)
+    G, _ = _shard_grad({k: v.astype(np.float64) for k, v in P.items()}, rec, m, lo, hi, teacher)
+    for key, view in zip(PARAM_KEYS, bucket.grad_views):      # what mcrn_model_backward does on the GPU
+        view.copy_(torch.from_numpy(G[key].astype(np.float32)))
+    bucket.allreduce()
+    q.put((rank, teacher, bucket.offsets, bucket.n, bucket.grad_scale, bucket.flat_g.numpy().copy(), after_bcast,
+           [v.data_ptr() == bucket.flat_p[o:o + 1].data_ptr() for v, o in zip(model._fused_params(), bucket.offsets)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_bucket_allreduce_and_grad_scale_world2():
+    from megacrn_amd._lib import PARAM_KEYS
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rec, P, m = load_case("tiny", "f32")
+    (_, teacher, offsets, n, scale, g0, sd0, is_view), (_, teacher1, _, _, _, g1, sd1, _) = res
+    assert teacher == teacher1 and scale == 0.5 and all(is_view)
+    assert all(o % 64 == 0 for o in offsets) and n % 64 == 0
+    np.testing.assert_array_equal(g0, g1)                       # one all-reduce leaves identical buckets
+    for k in P:                                                 # rank 0's weights won the broadcast, through the views
+        np.testing.assert_array_equal(sd0[k], P[k]); np.testing.assert_array_equal(sd1[k], P[k])
+    # the bucket, scaled by grad_scale, is the mean of the shard gradients = the oracle's DP gradient ...
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    shard = [_shard_grad(P64, rec, m, r, r + 1, teacher)[0] for r in range(world)]
+    for key, off in zip(PARAM_KEYS, offsets):
+        want = sum(g[key] for g in shard) / world
+        got = g0[off:off + want.size].reshape(want.shape) * scale
+        assert relerr(got, want) < 1e-6, key
+    # ... and what clip + Adam then does with it is the single-process step on those mean gradients
+    Gm = {k: sum(g[k] for g in shard) / world for k in P64}
+    tot = O.clip_grad_norm(Gm, 5.0)
+    flat = np.concatenate([(g0[o:o + P[k].size] * scale) for k, o in zip(PARAM_KEYS, offsets)])
+    assert abs(np.sqrt((flat.astype(np.float64) ** 2).sum()) - tot) < 1e-5 * tot

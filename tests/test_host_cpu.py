@@ -103,3 +103,74 @@ def test_train_cli_defaults_match_reference_flags():
     x, y = synthetic_windows(5, 12, 7, 0)
     assert x.shape == (5, 12, 7, 2) and y.shape == (5, 12, 7, 2)
     assert (x[..., 0] == 0).mean() > 0.02 and 0 <= x[..., 1].min() and x[..., 1].max() < 1
+
+
+def test_unchanged_reference_import_resolves_the_shim():
+    """model/traintest_MegaCRN.py:15 is `from MegaCRN import MegaCRN` with the model directory on sys.path.
+    With megacrn_amd/ first on sys.path instead, the same statement must yield the HIP-backed class,
+    constructed with the trainer's get_model() keywords (:28-30).  Fresh interpreter, cwd outside the repo."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from MegaCRN import MegaCRN\n"
+        "import megacrn_amd.modules as mm\n"
+        "assert MegaCRN is mm.MegaCRN\n"
+        "m = MegaCRN(num_nodes=7, input_dim=1, output_dim=1, horizon=3, rnn_units=4, num_layers=1, mem_num=3,\n"
+        "            mem_dim=4, cheb_k=3, cl_decay_steps=2000, use_curriculum_learning=True)\n"
+        "assert list(m.state_dict())[:4] == ['memory.Memory', 'memory.Wq', 'memory.We1', 'memory.We2']\n"
+        "import MegaCRN as shim\n"
+        "assert all(hasattr(shim, n) for n in ('AGCN', 'AGCRNCell', 'ADCRNN_Encoder', 'ADCRNN_Decoder', 'print_params'))\n"
+        "print('ok')\n") % os.path.join(ROOT, "megacrn_amd")
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+    # and as a sub-module of the package (which rebinds the package attribute to the module: it stays constructible)
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "import megacrn_amd, megacrn_amd.modules as mm\n"
+             "import megacrn_amd.MegaCRN as sub\n"
+             "assert sub.MegaCRN is mm.MegaCRN\n"
+             "m = megacrn_amd.MegaCRN(5, 1, 1, 2, 4)\n"
+             "assert isinstance(m, mm.MegaCRN)\n"
+             "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code2], cwd="/tmp", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+def test_loader_scaler_and_prepare_match_reference_fixtures(golden_dir):
+    """Counterpart DataLoader / StandardScaler / prepare_x_y host half against outputs of the reference's own
+    model/utils.py:6-54 and traintest_MegaCRN.py:33-48 (tests/golden/make_golden_utils.py)."""
+    from megacrn_amd.train import DataLoader, StandardScaler, split_x_y, build_parser
+    z = np.load(f"{golden_dir}/utils_f32.npz")
+    xs, ys = z["loader:xs"], z["loader:ys"]
+    size, nbatch, bs, seed = [int(v) for v in z["loader:meta"]]
+    np.random.seed(seed)
+    dl = DataLoader(xs, ys, bs, shuffle=True)
+    assert (dl.size, dl.num_batch) == (size, nbatch)
+    assert np.array_equal(np.concatenate([b[0] for b in dl.get_iterator()]), z["loader:shuffled_x"])
+    assert np.array_equal(np.concatenate([b[1] for b in dl.get_iterator()]), z["loader:shuffled_y"])
+    assert np.array_equal(list(DataLoader(xs, ys, bs).get_iterator())[-1][0], z["loader:plain_x_last"])
+    sc = StandardScaler(mean=xs[..., 0].mean(), std=xs[..., 0].std())
+    assert np.array_equal(np.array([sc.mean, sc.std]), z["scaler:mean_std"])
+    assert np.array_equal(sc.transform(xs[..., 0]), z["scaler:x0"])
+    assert np.array_equal(sc.inverse_transform(sc.transform(xs[..., 0])), z["scaler:roundtrip"])
+    args = build_parser().parse_args([])
+    x0, y0, y1 = split_x_y(z["prep:x"], z["prep:y"], args)
+    for got, want in ((x0, "prep:x0"), (y0, "prep:y0"), (y1, "prep:y1")):
+        assert got.dtype == np.float32 and np.array_equal(got, z[want]), want
+    # a rank's shard is the same slice of the same arrays
+    x0s, y0s, y1s = split_x_y(z["prep:x"], z["prep:y"], args, 1, 3)
+    assert np.array_equal(x0s, z["prep:x0"][1:3]) and np.array_equal(y1s, z["prep:y1"][1:3])
+
+
+def test_trainer_rejects_malformed_inputs_before_touching_the_library():
+    """FlatTrainer / MegaCRN.forward hand raw pointers to the C ABI: wrong shapes, dtypes and devices must raise
+    like the reference's torch.cat / stack would, not read out of bounds."""
+    import megacrn_amd
+    m = megacrn_amd.MegaCRN(5, 1, 1, 3, 4)
+    x, yc, y = torch.randn(2, 4, 5, 1), torch.randn(2, 3, 5, 1), torch.randn(2, 3, 5, 1)
+    for bad in ((x, yc[:, :2], y), (x, torch.randn(2, 3, 5, 2), y), (x, yc, torch.randn(3, 3, 5, 1)),
+                (torch.randn(2, 4, 6, 1), yc, y)):
+        with pytest.raises(ValueError):
+            m._check_inputs(*bad)
+    m._check_inputs(x, yc, y)
+    m._check_inputs(x, yc, None)

@@ -86,3 +86,21 @@ def test_ops(dn, golden_dir):
                      (gr["gate_w"], g("dgw")), (gr["gate_b"], g("dgb")),
                      (gr["update_w"], g("duw")), (gr["update_b"], g("dub"))):
             assert relerr(a, b) < tol
+
+
+def test_oracle_eval_metrics_match_reference_evaluate(golden_dir):
+    """The oracle's restatement of evaluate()'s figures (model/traintest_MegaCRN.py:63-93, model/utils.py:126-160)
+    against values computed by the reference's own statements (tests/golden/make_golden_utils.py)."""
+    z = np.load(f"{golden_dir}/utils_f32.npz")
+    B, T, N, D, nb = [int(v) for v in z["eval:meta"]]
+    rows = []
+    ypad = np.concatenate([z["eval:y"], np.repeat(z["eval:y"][-1:], nb * B - len(z["eval:y"]), axis=0)])   # loader padding
+    for i in range(nb):
+        y0 = ypad[i * B:(i + 1) * B, ..., :1].astype(np.float32)
+        outs = (z[f"eval:output{i}"], None, z[f"eval:query{i}"], z[f"eval:pos{i}"], z[f"eval:neg{i}"])
+        rows.append(O.eval_batch(outs, y0, SC_MEAN, SC_STD))
+    np.testing.assert_allclose(np.array(rows), z["eval:per_batch"], rtol=2e-5)
+    ep = O.eval_epoch(rows)
+    assert abs(ep[0] - float(z["eval:mean_loss"])) < 1e-5 * abs(ep[0])
+    logged = z["eval:logged"].reshape(-1)              # what the reference logs, 4 decimals
+    np.testing.assert_allclose(np.array(ep[1:]), logged, atol=6e-5)
