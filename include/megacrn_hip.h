@@ -40,6 +40,10 @@ extern "C" {
 #define MCRN_F32 0     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 157 TF peak */
 #define MCRN_BF16X3 1  /* fp32 operands split into bf16 hi+lo, 3x v_mfma_f32_32x32x16_bf16 with fp32
                           accumulate: ~1e-5 relative error, 5.3x the MFMA rate of MCRN_F32 (default) */
+#define MCRN_BF16 2    /* fused model entry points only: the K-hop propagation, its transpose and the adjacency
+                          gradient run on bf16-RESIDENT operands (one bf16 MFMA per product, fp32 accumulate; the
+                          Chebyshev terms as the reference's own matrices [S, 2SS-I], model/MegaCRN.py:20-22),
+                          everything else as MCRN_BF16X3.  Stated tolerance 2e-2 (tests); the large-graph mode. */
 
 typedef struct mcrn_dims {
     int B;          /* batch */
@@ -53,7 +57,7 @@ typedef struct mcrn_dims {
     int mem_num;    /* M */
     int mem_dim;    /* D */
     int cheb_k;     /* 2 or 3 */
-    int precision;  /* MCRN_F32 or MCRN_BF16X3 */
+    int precision;  /* MCRN_F32, MCRN_BF16X3 or MCRN_BF16 */
 } mcrn_dims_t;
 
 /* parameter pointers, named after the reference state_dict keys (num_layers=1) */

@@ -128,12 +128,13 @@ def _load():
 
 lib = _load()
 
-F32, BF16X3 = 0, 1
-PRECISIONS = {"f32": F32, "bf16x3": BF16X3}
+F32, BF16X3, BF16 = 0, 1, 2
+PRECISIONS = {"f32": F32, "bf16x3": BF16X3, "bf16": BF16}
 
 
 def default_precision() -> int:
-    """MEGACRN_PRECISION=f32|bf16x3 (default bf16x3: fp32-equivalent split on the bf16 matrix cores)."""
+    """MEGACRN_PRECISION=f32|bf16x3|bf16 (default bf16x3: fp32-equivalent split on the bf16 matrix cores; bf16:
+    bf16-resident propagation for large graphs, own tolerance)."""
     return PRECISIONS[os.environ.get("MEGACRN_PRECISION", "bf16x3")]
 
 

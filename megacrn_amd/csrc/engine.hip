@@ -23,6 +23,7 @@
 #include "gemm_bf16x3.h"
 #include "prop_small.h"
 #include "dgrad_stream.h"
+#include "gemm_bf16_api.h"
 #include "ops.h"
 
 namespace mcrn {
@@ -30,7 +31,9 @@ namespace mcrn {
 GemmStats g_gemm_stats = {0, 0.0};
 int g_force_cfg = -1;
 int g_debug = getenv("MCRN_DEBUG") ? atoi(getenv("MCRN_DEBUG")) : 0;   // tuning A/B bits, 0 in production
-static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch
+static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch (MCRN_F32 or MCRN_BF16X3)
+static bool g_prop_bf16 = false;        // MCRN_BF16: propagation / its transpose / adjacency gradient on bf16-resident operands
+                                        // (gemm_bf16.h); every other contraction keeps the bf16x3 arithmetic
 static char g_err[512] = "";
 static int g_launches = 0;
 
@@ -215,9 +218,12 @@ static void side_reset() { g_side.any = false; g_side.pending[0] = g_side.pendin
 // The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
 // thread per process (the launch model of bench.py / megacrn_amd.train: one process per GPU).
 struct PrecisionScope {
-    int saved;
-    explicit PrecisionScope(int p) : saved(g_precision) { g_precision = p; }
-    ~PrecisionScope() { g_precision = saved; }
+    int saved; bool saved_bf;
+    explicit PrecisionScope(int p) : saved(g_precision), saved_bf(g_prop_bf16) {
+        g_prop_bf16 = p == MCRN_BF16;
+        g_precision = p == MCRN_BF16 ? MCRN_BF16X3 : p;
+    }
+    ~PrecisionScope() { g_precision = saved; g_prop_bf16 = saved_bf; }
 };
 
 // ---- bump allocator over the caller's workspace -------------------------------------------
@@ -237,11 +243,12 @@ struct Shp {   // one AGCN / cell geometry
     int B, N, d, H, C, Cp, K, G;
     long long R, ld, PS, ZT;   // rows, plane row stride (per node), plane size, plane-set size
 };
-static Shp mk_shape(int B, int N, int d, int H, int K) {
+static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     Shp s;
     s.B = B; s.N = N; s.d = d; s.H = H; s.K = K;
     s.C = d + H;
     s.Cp = (s.C + 3) & ~3;
+    if (bf16_rows && ((long long)B * s.Cp) % 8) s.Cp = (s.C + 7) & ~7;   // bf16 plane rows are fetched in 16-byte chunks
     s.G = 2 * K - 1;
     s.R = (long long)N * B;
     s.ld = (long long)B * s.Cp;
@@ -264,6 +271,12 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     long long slab;
     long long sup_stride;   // floats between the slab sets of support 0 and 1
     bool defer;     // adjacency gradient is computed once per stack by ds_deferred_kernel
+    // MCRN_BF16 (gemm_bf16.h): stacked bf16 adjacency [S1; T2(S1); S2; T2(S2)] (rows padded to Kp) and its transpose
+    const uint16_t* Sstk = nullptr;
+    const uint16_t* STstk = nullptr;
+    const uint16_t* zero = nullptr;
+    int Kp = 0, nb = 0;
+    float *mu = nullptr, *mu_part = nullptr;    // column sums of a plane over its nodes (+ partials)
 };
 static int nslab_S(int N) {
     // N <= 256: one ds_small workgroup per slab; its slab read + write is ~9 us whatever its K range, so fewer,
@@ -291,8 +304,112 @@ static GemmP gp() {
     return p;
 }
 
+// ---- bf16-resident GEMM (gemm_bf16.h) with the library's profiling hooks and an on-device tile choice -------
+struct Bf16Key {
+    int btr, M, N, K, nsplit;
+    bool operator<(const Bf16Key& o) const { return memcmp(this, &o, sizeof(Bf16Key)) < 0; }
+};
+static std::map<Bf16Key, int> g_tuned_bf16;
+static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
+static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
+    // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
+    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.75, 1.0};
+    static const int per_cu[NCFG_BF16] = {2, 1, 1, 1};
+    int best = 0; double bt = 1e300;
+    for (int c = 0; c < NCFG_BF16; ++c) {
+        const long long tiles = (long long)cdiv(p.M, kCfgBf16[c][0]) * cdiv(p.N, kCfgBf16[c][1]) * nsplit;
+        const double rounds = ceil((double)tiles / (256.0 * per_cu[c]));
+        const double t = rounds * per_cu[c] * kCfgBf16[c][0] * kCfgBf16[c][1] / eff[c];
+        if (t < bt) { bt = t; best = c; }
+    }
+    return best;
+}
+static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, hipStream_t st) {
+    ++g_launches;
+    if (nsplit < 1) nsplit = 1;
+    const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len, nsplit};
+    int cfg = g_force_cfg_bf16;
+    if (cfg < 0 || cfg >= NCFG_BF16) {
+        auto it = g_tuned_bf16.find(key);
+        if (it != g_tuned_bf16.end()) cfg = it->second;
+        else if (g_tuning) {
+            if (!g_tune_ev_ok) {
+                CK(hipEventCreate(&g_tune_ev[0]));
+                CK(hipEventCreate(&g_tune_ev[1]));
+                g_tune_ev_ok = true;
+            }
+            float best_ms = 1e30f;
+            for (int c = 0; c < NCFG_BF16; ++c) {
+                CK(launch_gemm_bf16(p, btr, c, nsplit, st));                         // warm-up
+                CK(hipEventRecord(g_tune_ev[0], st));
+                for (int r = 0; r < 4; ++r) CK(launch_gemm_bf16(p, btr, c, nsplit, st));
+                CK(hipEventRecord(g_tune_ev[1], st));
+                CK(hipEventSynchronize(g_tune_ev[1]));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                if (ms < best_ms) { best_ms = ms; cfg = c; }
+            }
+            g_tuned_bf16[key] = cfg;
+        } else cfg = bf16_cfg_prior(p, nsplit);
+    }
+    const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
+    if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    CK(launch_gemm_bf16(p, btr, cfg, nsplit, st));
+    if (prof) {
+        CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+        const double ex = 2.0 * p.M * (double)p.N * (double)p.nseg * p.seg_len;
+        g_prof.exec_flops += ex;
+        g_prof.alg_flops += alg > 0 ? alg : ex;
+        ++g_prof.n;
+    }
+    return 0;
+}
+static Bf16GemmP bgp(const Sup& u) {
+    Bf16GemmP p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.nsplit = 1; p.zero = u.zero; p.xcd = 1;
+    return p;
+}
+// plane (N x ld fp32) -> bf16 copy (propagation operand) and node-centred bf16 copy (adjacency-gradient operand)
+static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st);
+
+// MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
+//   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
+// T2(S) = 2 S S - I is the reference's own matrix form (model/MegaCRN.py:20-22), built once per step.
+static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, uint16_t* x0c, hipStream_t st) {
+    CKI(plane_to_bf16(s, u, Z, x0b, x0c, st));
+    Bf16GemmP p = bgp(u);
+    p.A = u.Sstk; p.am = rm_plain(u.Kp); p.M = u.nb * s.N;
+    p.B = x0b; p.ldb = s.ld; p.N = (int)s.ld;
+    p.nseg = 1; p.seg_len = s.N; p.a_seg = 0; p.b_seg = 0;
+    p.C = Z + s.PS; p.cm = rm_two(s.N, s.PS, s.ld);
+    return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+}
+// MCRN_BF16 backward propagation: dP[0] += [S1^T | T2(S1)^T | S2^T | T2(S2)^T] x [dP[1]; ..; dP[nb]]  (K = nb*N)
+static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, hipStream_t st) {
+    Bf16GemmP p = bgp(u);
+    p.A = u.STstk; p.am = rm_plain((long long)u.nb * u.Kp); p.M = s.N;
+    p.B = dPb; p.ldb = s.ld; p.N = (int)s.ld;
+    p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PS;
+    p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
+    return bf16_gemm(p, true, 1, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+}
+// MCRN_BF16 adjacency gradient of a whole cell stack, ONE launch: K runs over every AGCN call of the stack
+//   dA[b] (N x N) (+)= sum_calls dP_call[1 + b] (N x B*Cp) x (X0_call - mean)^T        b < nb
+static int ds_bf16(const Shp& s, const Sup& u, const uint16_t* dPb_all, const uint16_t* x0c_all, int ncalls, float* dA,
+                   long long ldS, bool accumulate, hipStream_t st) {
+    Bf16GemmP p = bgp(u);
+    p.A = dPb_all; p.am = rm_two(s.N, s.PS, s.ld); p.M = u.nb * s.N;
+    p.B = x0c_all; p.bm = rm_plain(s.ld); p.N = s.N;
+    p.nseg = ncalls; p.seg_len = (int)s.ld; p.a_seg = (long long)u.nb * s.PS; p.b_seg = s.PS;
+    p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS);
+    if (accumulate) { p.Cin = dA; p.beta = 1.f; }
+    return bf16_gemm(p, false, 1, ROLE_DS, (double)ncalls * u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+}
+
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
-static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
+static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr) {
+    if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st);
     if (use_prop_small(u, s) && aligned16(Z) && s.K == 3) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
@@ -359,7 +476,7 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
-                         float* dT = nullptr, bool* used_dT = nullptr) {
+                         float* dT = nullptr, bool* used_dT = nullptr, uint16_t* dPb = nullptr) {
     if (used_dT) *used_dT = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
@@ -377,6 +494,13 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
         if (imgd && g_precision == MCRN_BF16X3) { p.Bimg = imgd; p.bimg_n = (s.G * s.Cp + 3) & ~3; }
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
+    }
+    if (g_prop_bf16 && u.STstk && dPb) {
+        // planes 1.. of dP as bf16 (operand of the S^T product now, of the stack's adjacency gradient later)
+        const long long n8 = (long long)u.nb * s.PS / 8;
+        LAUNCH(k_plane_to_bf16, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const float*)(dP + s.PS), n8, (int)s.ld,
+               reinterpret_cast<uint4*>(dPb), (uint4*)nullptr, (const float*)nullptr, 0.f);
+        return prop_bwd_bf16(s, u, dP, dPb, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
     const bool fused_bwd = small && s.K == 3 && dT != nullptr;
@@ -516,25 +640,35 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
 
 static const int COLSUM_CHUNK = 512;
 static int colsum(const float* X, long long ld, long long rows, int C, float* part, float* out,
-                  int accumulate, hipStream_t st) {
-    const int nchunk = cdiv(rows, COLSUM_CHUNK);
-    LAUNCH(k_colsum_stage1, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, X, ld, rows, C, COLSUM_CHUNK, part);
+                  int accumulate, hipStream_t st, int chunk = COLSUM_CHUNK) {
+    const int nchunk = cdiv(rows, chunk);
+    LAUNCH(k_colsum_stage1, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, X, ld, rows, C, chunk, part);
     LAUNCH(k_colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, (const float*)part, nchunk, C, out, accumulate);
     return 0;
 }
-static size_t colsum_part_floats(long long rows, int C) { return (size_t)cdiv(rows, COLSUM_CHUNK) * C; }
+static size_t colsum_part_floats(long long rows, int C, int chunk = COLSUM_CHUNK) { return (size_t)cdiv(rows, chunk) * C; }
+static const int MU_CHUNK = 64;       // rows per partial of the node-mean of a plane (wide grid: N / 64 x ld / 64 workgroups)
+static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st) {
+    const long long n8 = s.PS / 8;
+    if (xc) CKI(colsum(X, s.ld, s.N, (int)s.ld, u.mu_part, u.mu, 0, st, MU_CHUNK));
+    LAUNCH(k_plane_to_bf16, dim3(cdiv(n8, 256)), dim3(256), 0, st, X, n8, (int)s.ld, reinterpret_cast<uint4*>(xb),
+           reinterpret_cast<uint4*>(xc), (const float*)u.mu, 1.f / (float)s.N);
+    return 0;
+}
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
 struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr; };
 
+// x0b / x0c: bf16 slots of this cell's two AGCN calls (gate first, update second), or nullptr
 static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* zr, float* hc,
-                         const CellW& w, float* hnext, long long hnext_ld, hipStream_t st) {
-    CKI(prop_fwd(s, u, Z, st));
+                         const CellW& w, float* hnext, long long hnext_ld, hipStream_t st, uint16_t* x0b = nullptr,
+                         uint16_t* x0c = nullptr) {
+    CKI(prop_fwd(s, u, Z, st, x0b, x0c));
     GemmP e = gp();
     e.epi = EPI_GATE; e.C[0] = zr; e.bias = w.bg; e.hsrc = Z; e.hsrc_ld = s.Cp;
     e.out2 = Y; e.out2_ld = s.Cp; e.H = s.H;
     CKI(wp_fwd(s, Z, w.Wf_g, 2 * s.H, e, st, w.if_g));
-    CKI(prop_fwd(s, u, Y, st));
+    CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PS : nullptr, x0c ? x0c + s.PS : nullptr));
     e = gp();
     e.epi = EPI_UPDATE; e.C[0] = hc; e.bias = w.bu; e.hsrc = Z; e.hsrc_ld = s.Cp; e.zr = zr;
     e.out2 = hnext; e.out2_ld = hnext_ld; e.H = s.H;
@@ -547,13 +681,13 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
                          float* dTg = nullptr, bool do_a = true, bool do_c = true, bool* xu_out = nullptr,
-                         bool* xg_out = nullptr) {
+                         bool* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */) {
     const long long RH = s.R * s.H;
     bool xu = false, xg = false;
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu));
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PS : nullptr));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg));
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg, dPb));
     if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
@@ -719,7 +853,7 @@ static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long l
 static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st, uint4* imgf = nullptr,
                  uint4* imgd = nullptr) {
     long long tot = (long long)s.G * s.Cp * O;
-    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O);
+    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, g_prop_bf16 ? 0 : 1);
     if (imgf && g_precision == MCRN_BF16X3) {
         const int Kp = s.G * s.Cp;
         {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
@@ -768,6 +902,12 @@ struct ModelPlan {
     float *dval, *dsc, *dq;
     float *dWq_s, *dMem_s, *dWp_s;
     float *part, *part2;
+    // MCRN_BF16: stacked bf16 adjacency and its transpose, T2 matrices, per-call bf16 operands, adjacency-gradient blocks
+    bool bf16;
+    int nb, Kp;
+    uint16_t *Sstk, *STstk, *bfzero;
+    float *T2[2], *dA, *mu, *mu_part;
+    uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     size_t total;
 };
 
@@ -777,7 +917,8 @@ static int check_dims(const mcrn_dims_t* d) {
         d->ycov_dim < 0 || d->H < 1 || d->mem_num < 1 || d->mem_dim < 1)
         FAIL("mcrn_dims: all sizes must be >= 1");
     if (d->cheb_k != 2 && d->cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", d->cheb_k);
-    if (d->precision != MCRN_F32 && d->precision != MCRN_BF16X3) FAIL("unsupported precision %d", d->precision);
+    if (d->precision != MCRN_F32 && d->precision != MCRN_BF16X3 && d->precision != MCRN_BF16)
+        FAIL("unsupported precision %d", d->precision);
     return 0;
 }
 
@@ -785,8 +926,9 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     Bump b{base, 0};
     const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num, K = d->cheb_k;
     const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim;
-    P.se = mk_shape(B, N, d->input_dim, H, K);
-    P.sd = mk_shape(B, N, od + yd, Hd, K);
+    P.bf16 = d->precision == MCRN_BF16;
+    P.se = mk_shape(B, N, d->input_dim, H, K, P.bf16);
+    P.sd = mk_shape(B, N, od + yd, Hd, K, P.bf16);
     P.ldS = (N + 3) & ~3;
     P.nslabS = nslab_S(N);
     plan_sup(b, N, M, D, P.ldS, P.sup);
@@ -849,6 +991,25 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     int Tm = d->T_in > d->T_out ? d->T_in : d->T_out;
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
+    P.nb = 2 * (K - 1); P.Kp = (N + 63) & ~63;
+    P.Sstk = P.STstk = P.bfzero = nullptr; P.T2[0] = P.T2[1] = P.dA = P.mu = P.mu_part = nullptr;
+    P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
+    if (P.bf16) {
+        P.bfzero = b.take<uint16_t>(128);
+        P.Sstk = b.take<uint16_t>((size_t)P.nb * N * P.Kp);
+        P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
+        for (int i = 0; i < 2; ++i) P.T2[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;
+        P.dA = b.take<float>((size_t)P.nb * N * P.ldS);
+        const long long ldm = P.se.ld > P.sd.ld ? P.se.ld : P.sd.ld;
+        P.mu = b.take<float>((size_t)ldm);
+        P.mu_part = b.take<float>(colsum_part_floats(N, (int)ldm, MU_CHUNK) + 1024);
+        P.x0b_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PS);
+        P.x0c_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PS);
+        P.x0b_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PS);
+        P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PS);
+        P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PS);
+        P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PS);
+    }
     P.total = (b.off + 255) & ~(size_t)255;
 }
 
@@ -863,7 +1024,66 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
     u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
     u.defer = false;
+    u.Sstk = P.Sstk; u.STstk = P.STstk; u.zero = P.bfzero; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
     return u;
+}
+
+// MCRN_BF16, once per forward: T2(S) = 2 S S - I (model/MegaCRN.py:20-22), then the stacked bf16 operands
+static int build_stacks(const ModelPlan& P, int N, int K, hipStream_t st) {
+    CK(hipMemsetAsync(P.bfzero, 0, 256, st));
+    const float* blk[4];
+    int nblk = 0;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const float* S = sidx ? P.sup.g2 : P.sup.g1;
+        blk[nblk++] = S;
+        if (K == 3) {
+            GemmP q = gp();
+            q.M = N; q.N = N; q.K = N;
+            q.A[0] = S; q.am = plain(P.ldS); q.ak = plain(1);
+            q.B[0] = S; q.bk = plain(P.ldS); q.bn = plain(1);
+            q.C[0] = P.T2[sidx]; q.cm = plain(P.ldS); q.cn = plain(1);
+            q.alpha = 2.f;
+            CKI(gemm(q, true, false, 0, ROLE_MISC, st));
+            LAUNCH(k_sub_eye, dim3(cdiv(N, 256)), dim3(256), 0, st, P.T2[sidx], P.ldS, N);
+            blk[nblk++] = P.T2[sidx];
+        }
+    }
+    const dim3 g(cdiv(P.Kp, 32), cdiv(N, 32));
+    for (int b_ = 0; b_ < nblk; ++b_) {
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, blk[b_], P.ldS, N, P.Kp, 0, P.Sstk, (long long)P.Kp, (long long)b_ * N, 0LL);
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, blk[b_], P.ldS, N, P.Kp, 1, P.STstk, (long long)nblk * P.Kp, 0LL,
+               (long long)b_ * P.Kp);
+    }
+    return 0;
+}
+// MCRN_BF16, once per backward: chain rule of T2 = 2 S S - I onto S, in place in the S blocks of dA
+//   dS = dA[S] + 2 (dT S^T + S^T dT),  dT = dA[T2]
+static int t2_backward(const ModelPlan& P, int N, int K, hipStream_t st) {
+    if (K != 3) return 0;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const float* S = sidx ? P.sup.g2 : P.sup.g1;
+        float* dS = P.dA + (long long)(2 * sidx) * N * P.ldS;
+        const float* dT = P.dA + (long long)(2 * sidx + 1) * N * P.ldS;
+        {   // dS += 2 dT S^T
+            GemmP q = gp();
+            q.M = N; q.N = N; q.K = N;
+            q.A[0] = dT; q.am = plain(P.ldS); q.ak = plain(1);
+            q.B[0] = S; q.bk = plain(1); q.bn = plain(P.ldS);
+            q.C[0] = dS; q.Cin[0] = dS; q.cm = plain(P.ldS); q.cn = plain(1);
+            q.alpha = 2.f; q.beta = 1.f;
+            CKI(gemm(q, true, true, 0, ROLE_MISC, st));
+        }
+        {   // dS += 2 S^T dT
+            GemmP q = gp();
+            q.M = N; q.N = N; q.K = N;
+            q.A[0] = S; q.am = plain(1); q.ak = plain(P.ldS);
+            q.B[0] = dT; q.bk = plain(P.ldS); q.bn = plain(1);
+            q.C[0] = dS; q.Cin[0] = dS; q.cm = plain(P.ldS); q.cn = plain(1);
+            q.alpha = 2.f; q.beta = 1.f;
+            CKI(gemm(q, false, false, 0, ROLE_MISC, st));
+        }
+    }
+    return 0;
 }
 
 // q = h Wq and sc = q Mem^T on the MFMA GEMM, then one light row kernel (softmax, top-2, value, outputs)
@@ -965,7 +1185,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const int Ti = d->T_in, To = d->T_out;
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
-    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, true, st));
+    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
+    if (P.bf16) CKI(build_stacks(P, N, d->cheb_k, st));
     Sup u = model_sup(P, N);
     const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
@@ -979,7 +1200,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     for (int t = 0; t < Ti; ++t)
         CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
-                          we, P.Zenc + (t + 1) * se.ZT, se.Cp, st));
+                          we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PS : nullptr,
+                          P.bf16 ? P.x0c_e + (long long)2 * t * se.PS : nullptr));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
                           P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
@@ -996,7 +1218,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
         CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
-                          P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st));
+                          P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PS : nullptr,
+                          P.bf16 ? P.x0c_d + (long long)2 * t * sd.PS : nullptr));
         const bool last = t + 1 == To;
         const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;
         LAUNCH(k_proj_fwd, dim3(cdiv(R, 4) < 2048 ? cdiv(R, 4) : 2048), dim3(256), 0, st, (const float*)Zn,
@@ -1067,7 +1290,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             }
             CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
-                              P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg));
+                              P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg,
+                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PS : nullptr));
             dPprev = dPt; dQprev = dQt;
         }
     }
@@ -1123,7 +1347,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                                 P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
-                              P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg));
+                              P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
+                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PS : nullptr));
         }
     }
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
@@ -1134,6 +1359,15 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
     // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
     CKI(side_join(st));
+    if (P.bf16) {
+        // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
+        // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
+        CKI(ds_bf16(sd, u, P.dPb_d, P.x0c_d, 2 * To, P.dA, P.ldS, false, st));
+        CKI(ds_bf16(se, u, P.dPb_e, P.x0c_e, 2 * Ti, P.dA, P.ldS, true, st));
+        CKI(t2_backward(P, N, d->cheb_k, st));
+        CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
+                         P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st));
+    } else
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
                      P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st));
     LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_W,
@@ -1309,8 +1543,8 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
 int mcrn_autotune_entries(void) { return (int)g_tuned.size(); }
 int mcrn_autotune_clear(void) { g_tuned.clear(); return 0; }
 int mcrn_set_precision(int precision) {
-    if (precision != MCRN_F32 && precision != MCRN_BF16X3) FAIL("unsupported precision %d", precision);
-    g_precision = precision;
+    if (precision != MCRN_F32 && precision != MCRN_BF16X3 && precision != MCRN_BF16) FAIL("unsupported precision %d", precision);
+    g_precision = precision == MCRN_BF16 ? MCRN_BF16X3 : precision;   // the stand-alone ops have no bf16-resident form
     return 0;
 }
 int mcrn_get_precision(void) { return g_precision; }

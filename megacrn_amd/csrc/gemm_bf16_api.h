@@ -1,0 +1,47 @@
+// gemm_bf16_api.h - parameter block and host entry point of the bf16-resident GEMM (kernels: gemm_bf16.h, compiled in
+// gemm_bf16_unit.hip).  engine.hip includes only this file, so the kernels can be rebuilt without it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcrn {
+
+struct RowMap {           // off(r) = (r / inner) * hi + (r % inner) * lo ; inner <= 0: r * lo
+    int inner;
+    long long hi, lo;
+};
+static inline RowMap rm_plain(long long lo) { return RowMap{0, 0, lo}; }
+static inline RowMap rm_two(int inner, long long hi, long long lo) { return RowMap{inner, hi, lo}; }
+__host__ __device__ __forceinline__ long long rm_off(const RowMap& m, int r) {
+    if (m.inner <= 0) return (long long)r * m.lo;
+    const int q = r / m.inner;
+    return (long long)q * m.hi + (long long)(r - q * m.inner) * m.lo;
+}
+
+struct Bf16GemmP {
+    const uint16_t* A;        // bf16 bits
+    const uint16_t* B;
+    RowMap am;                // A row m -> element offset of (m, k = 0) inside a segment
+    RowMap bm;                // NT: B row n -> element offset ; NN: unused
+    long long ldb;            // NN: elements between consecutive k rows of B
+    int nseg, seg_len, tps;   // K segments, valid k per segment (multiple of 8), k-tiles per segment = ceil(seg_len/64)
+    long long a_seg, b_seg;   // element offset between segments
+    int M, N;                 // valid rows of A ; valid columns (NT: rows of B; NN: multiple of 8)
+    float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
+    const float* Cin;         // nullable
+    RowMap cm;                // C row m -> element offset, columns contiguous
+    float alpha, beta;
+    int nsplit, tiles_per_split;   // split-K over k-tiles ; C / Cin of split z at + z * slab
+    long long slab;
+    uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
+    RowMap cbm;
+    const uint16_t* zero;     // >= 16 bytes of zeros
+    int xcd;                  // 1: XCD-aware tile order
+};
+
+// fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
+hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st);
+static const int NCFG_BF16 = 4;
+static const int kCfgBf16[NCFG_BF16][4] = {{128, 128, 2, 2}, {256, 128, 4, 2}, {128, 256, 2, 4}, {256, 256, 2, 4}};
+
+}  // namespace mcrn

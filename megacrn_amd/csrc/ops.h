@@ -87,7 +87,7 @@ __global__ void k_rows_to_bnc(float* __restrict__ dst, const float* __restrict__
 // folded in for cheb_k = 3 (plane0 -= W_2 blocks, k=2 planes *= 2).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_wprep(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wd,
-                        int d, int H, int Cp, int K, int O) {
+                        int d, int H, int Cp, int K, int O, int fold) {
     const int G = 2 * K - 1, C = d + H;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long tot = (long long)G * Cp * O;
@@ -103,14 +103,14 @@ __global__ void k_wprep(const float* __restrict__ W, float* __restrict__ Wf, flo
             float w1 = W[((long long)(1 * K + 0) * C + cref) * O + o];
             wf = w0 + w1;
             wd = wf;
-            if (K == 3) {
+            if (K == 3 && fold) {
                 wd -= W[((long long)(0 * K + 2) * C + cref) * O + o];
                 wd -= W[((long long)(1 * K + 2) * C + cref) * O + o];
             }
         } else {
             int s = (g - 1) / (K - 1), k = 1 + (g - 1) % (K - 1);
             wf = W[((long long)(s * K + k) * C + cref) * O + o];
-            wd = (k == 2) ? 2.f * wf : wf;
+            wd = (k == 2 && fold) ? 2.f * wf : wf;   // fold == 0 (MCRN_BF16): the planes are T_k(S) x, no recursion to fold
         }
     }
     Wf[i] = wf;
@@ -779,6 +779,73 @@ __global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float*
     p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16-resident operands of the large-graph path (MCRN_BF16, gemm_bf16.h)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bf16_rne(float f) {        // finite values
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// dst[i] = bf16(src[i]) and optionally cen[i] = bf16(src[i] - colsum[i % ld] * inv_rows), 8 elements per thread
+// (ld % 8 == 0).  `cen` is the plane centred over its rows (nodes): the adjacency gradient dP x X^T only enters the
+// row-softmax backward, which is blind to anything constant along a row of dS, so the node-mean of X can be removed
+// BEFORE rounding to bf16 - that mean is what makes the softmax backward cancel catastrophically on large graphs.
+__global__ void k_plane_to_bf16(const float* __restrict__ src, long long n8, int ld, uint4* __restrict__ dst,
+                                uint4* __restrict__ cen, const float* __restrict__ colsum, float inv_rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (dst) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = bf16_rne(v[2 * j]) | (bf16_rne(v[2 * j + 1]) << 16);
+        dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (cen) {
+        const int c0 = (int)((8 * i) % ld);
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = colsum[c0 + 2 * j] * inv_rows, m1 = colsum[c0 + 2 * j + 1] * inv_rows;
+            w[j] = bf16_rne(v[2 * j] - m0) | (bf16_rne(v[2 * j + 1] - m1) << 16);
+        }
+        cen[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// One block of the stacked adjacency operand of the propagation GEMM (model/MegaCRN.py:20-25 as ONE product):
+//   transpose == 0:  dst[(r0 + i) * ldd + c0 + j] = bf16(S[i][j])        forward stack  [S1; T2(S1); S2; T2(S2)]
+//   transpose == 1:  dst[(r0 + i) * ldd + c0 + j] = bf16(S[j][i])        backward stack [S1^T | T2^T | S2^T | T2^T]
+// for i < N, j < Kp (zero for j >= N: the K padding of the GEMM's A operand).  32 x 32 tiles through LDS.
+__global__ void k_stack_build(const float* __restrict__ S, long long lds_, int N, int Kp, int transpose,
+                              uint16_t* __restrict__ dst, long long ldd, long long r0, long long c0) {
+    __shared__ float t[32][33];
+    const int bi = blockIdx.y * 32, bj = blockIdx.x * 32;       // output tile origin (i, j)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads
+    for (int k = ty; k < 32; k += 8) {
+        if (transpose) {           // need S[j][i]: read rows j = bj + k, columns i = bi + tx
+            const int j = bj + k, i = bi + tx;
+            t[k][tx] = (j < N && i < N) ? S[(long long)j * lds_ + i] : 0.f;
+        } else {
+            const int i = bi + k, j = bj + tx;
+            t[k][tx] = (i < N && j < N) ? S[(long long)i * lds_ + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int i = bi + k, j = bj + tx;
+        if (i < N && j < Kp) dst[(r0 + i) * ldd + c0 + j] = (uint16_t)bf16_rne(transpose ? t[tx][k] : t[k][tx]);
+    }
+}
+
+// T2 = 2 S S - I was left as 2 S S by the GEMM: subtract the identity
+__global__ void k_sub_eye(float* __restrict__ A, long long ld, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) A[(long long)i * ld + i] -= 1.f;
+}
 
 // ---------------------------------------------------------------------------------------------
 // evaluation metrics of the trainer, ONE launch per batch, accumulated on device, no host sync

