@@ -242,6 +242,7 @@ struct Bump {
 struct Shp {   // one AGCN / cell geometry
     int B, N, d, H, C, Cp, K, G;
     long long R, ld, PS, ZT;   // rows, plane row stride (per node), plane size, plane-set size
+    int Kp; long long ldp, PSb;   // MCRN_BF16: bf16 planes are [Kp = roundup(N, 64)][ldp = roundup(ld, 64)], zero padded
 };
 static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     Shp s;
@@ -254,6 +255,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.ld = (long long)B * s.Cp;
     s.PS = s.R * s.Cp;
     s.ZT = s.PS * s.G;
+    s.Kp = (N + 63) & ~63; s.ldp = (s.ld + 63) & ~63LL; s.PSb = (long long)s.Kp * s.ldp;
     return s;
 }
 
@@ -274,7 +276,6 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     // MCRN_BF16 (gemm_bf16.h): stacked bf16 adjacency [S1; T2(S1); S2; T2(S2)] (rows padded to Kp) and its transpose
     const uint16_t* Sstk = nullptr;
     const uint16_t* STstk = nullptr;
-    const uint16_t* zero = nullptr;
     int Kp = 0, nb = 0;
     float *mu = nullptr, *mu_part = nullptr;    // column sums of a plane over its nodes (+ partials)
 };
@@ -313,13 +314,13 @@ static std::map<Bf16Key, int> g_tuned_bf16;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
-    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.75, 1.0};
-    static const int per_cu[NCFG_BF16] = {2, 1, 1, 1};
+    static const double eff[NCFG_BF16] = {0.6, 0.8, 1.0, 0.9, 0.9, 0.9, 0.85, 0.7};
     int best = 0; double bt = 1e300;
     for (int c = 0; c < NCFG_BF16; ++c) {
+        const int per_cu = kCfgBf16[c][2];
         const long long tiles = (long long)cdiv(p.M, kCfgBf16[c][0]) * cdiv(p.N, kCfgBf16[c][1]) * nsplit;
-        const double rounds = ceil((double)tiles / (256.0 * per_cu[c]));
-        const double t = rounds * per_cu[c] * kCfgBf16[c][0] * kCfgBf16[c][1] / eff[c];
+        const double rounds = ceil((double)tiles / (256.0 * per_cu));
+        const double t = rounds * per_cu * kCfgBf16[c][0] * kCfgBf16[c][1] / eff[c];
         if (t < bt) { bt = t; best = c; }
     }
     return best;
@@ -367,11 +368,13 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
 static Bf16GemmP bgp(const Sup& u) {
     Bf16GemmP p;
     memset(&p, 0, sizeof p);
-    p.alpha = 1.f; p.nsplit = 1; p.zero = u.zero; p.xcd = 1;
+    p.alpha = 1.f; p.nsplit = 1; p.xcd = 1;
     return p;
 }
 // plane (N x ld fp32) -> bf16 copy (propagation operand) and node-centred bf16 copy (adjacency-gradient operand)
 static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st);
+static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
+                          int nvalid);
 
 // MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
 //   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
@@ -380,28 +383,37 @@ static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, ui
     CKI(plane_to_bf16(s, u, Z, x0b, x0c, st));
     Bf16GemmP p = bgp(u);
     p.A = u.Sstk; p.am = rm_plain(u.Kp); p.M = u.nb * s.N;
-    p.B = x0b; p.ldb = s.ld; p.N = (int)s.ld;
+    p.B = x0b; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = 1; p.seg_len = s.N; p.a_seg = 0; p.b_seg = 0;
     p.C = Z + s.PS; p.cm = rm_two(s.N, s.PS, s.ld);
     return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
 }
 // MCRN_BF16 backward propagation: dP[0] += [S1^T | T2(S1)^T | S2^T | T2(S2)^T] x [dP[1]; ..; dP[nb]]  (K = nb*N)
-static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, hipStream_t st) {
+// The output is only N x B*Cp (135 / 255 tiles of 128 x 128 at EXPY-TKY) while K is nb*N deep: K is split in two, the
+// second half lands in the extra plane dT that the element-wise consumers of dP[0] add (same mechanism as the fused
+// S^T chain of the small-graph path), so no reduction pass and still one writer per element.
+static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, bool* used_dT, hipStream_t st) {
     Bf16GemmP p = bgp(u);
     p.A = u.STstk; p.am = rm_plain((long long)u.nb * u.Kp); p.M = s.N;
-    p.B = dPb; p.ldb = s.ld; p.N = (int)s.ld;
-    p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PS;
+    p.B = dPb; p.ldb = s.ldp; p.N = (int)s.ld;
+    p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PSb;
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
-    return bf16_gemm(p, true, 1, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+    int nsplit = 1;
+    static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 2;
+    if (dT && used_dT && split_env == 2 && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
+        nsplit = 2; p.slab = dT - dP; p.cin_first_only = 1;
+        *used_dT = true;
+    }
+    return bf16_gemm(p, true, nsplit, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
 }
 // MCRN_BF16 adjacency gradient of a whole cell stack, ONE launch: K runs over every AGCN call of the stack
 //   dA[b] (N x N) (+)= sum_calls dP_call[1 + b] (N x B*Cp) x (X0_call - mean)^T        b < nb
 static int ds_bf16(const Shp& s, const Sup& u, const uint16_t* dPb_all, const uint16_t* x0c_all, int ncalls, float* dA,
                    long long ldS, bool accumulate, hipStream_t st) {
     Bf16GemmP p = bgp(u);
-    p.A = dPb_all; p.am = rm_two(s.N, s.PS, s.ld); p.M = u.nb * s.N;
-    p.B = x0c_all; p.bm = rm_plain(s.ld); p.N = s.N;
-    p.nseg = ncalls; p.seg_len = (int)s.ld; p.a_seg = (long long)u.nb * s.PS; p.b_seg = s.PS;
+    p.A = dPb_all; p.am = rm_two(s.N, s.PSb, s.ldp); p.M = u.nb * s.N;
+    p.B = x0c_all; p.bm = rm_plain(s.ldp); p.N = s.N;
+    p.nseg = ncalls; p.seg_len = (int)s.ld; p.a_seg = (long long)u.nb * s.PSb; p.b_seg = s.PSb;
     p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS);
     if (accumulate) { p.Cin = dA; p.beta = 1.f; }
     return bf16_gemm(p, false, 1, ROLE_DS, (double)ncalls * u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
@@ -497,10 +509,8 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     }
     if (g_prop_bf16 && u.STstk && dPb) {
         // planes 1.. of dP as bf16 (operand of the S^T product now, of the stack's adjacency gradient later)
-        const long long n8 = (long long)u.nb * s.PS / 8;
-        LAUNCH(k_plane_to_bf16, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const float*)(dP + s.PS), n8, (int)s.ld,
-               reinterpret_cast<uint4*>(dPb), (uint4*)nullptr, (const float*)nullptr, 0.f);
-        return prop_bwd_bf16(s, u, dP, dPb, st);
+        CKI(planes_to_bf16(s, dP + s.PS, u.nb, dPb, nullptr, nullptr, st, -1));
+        return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
     const bool fused_bwd = small && s.K == 3 && dT != nullptr;
@@ -648,12 +658,20 @@ static int colsum(const float* X, long long ld, long long rows, int C, float* pa
 }
 static size_t colsum_part_floats(long long rows, int C, int chunk = COLSUM_CHUNK) { return (size_t)cdiv(rows, chunk) * C; }
 static const int MU_CHUNK = 64;       // rows per partial of the node-mean of a plane (wide grid: N / 64 x ld / 64 workgroups)
-static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st) {
-    const long long n8 = s.PS / 8;
-    if (xc) CKI(colsum(X, s.ld, s.N, (int)s.ld, u.mu_part, u.mu, 0, st, MU_CHUNK));
-    LAUNCH(k_plane_to_bf16, dim3(cdiv(n8, 256)), dim3(256), 0, st, X, n8, (int)s.ld, reinterpret_cast<uint4*>(xb),
-           reinterpret_cast<uint4*>(xc), (const float*)u.mu, 1.f / (float)s.N);
+static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
+                          int nvalid = -1) {
+    const long long n = (long long)np * s.Kp * (s.ldp / 8);
+    LAUNCH(k_plane_to_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, X, s.PS, s.N, (int)s.ld, nvalid < 0 ? (int)s.ld : nvalid, s.Kp,
+           (int)s.ldp, np,
+           reinterpret_cast<uint4*>(xb), reinterpret_cast<uint4*>(xc), mu, 1.f / (float)s.N);
     return 0;
+}
+static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st) {
+    if (xc) {
+        const int nsamp = s.N < 64 ? s.N : 64;
+        LAUNCH(k_colsum_sample, dim3(cdiv(s.ld, 64)), dim3(256), 0, st, X, s.ld, s.N, (int)s.ld, nsamp, u.mu);
+    }
+    return planes_to_bf16(s, X, 1, xb, xc, u.mu, st, -1);
 }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
@@ -668,7 +686,7 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
     e.epi = EPI_GATE; e.C[0] = zr; e.bias = w.bg; e.hsrc = Z; e.hsrc_ld = s.Cp;
     e.out2 = Y; e.out2_ld = s.Cp; e.H = s.H;
     CKI(wp_fwd(s, Z, w.Wf_g, 2 * s.H, e, st, w.if_g));
-    CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PS : nullptr, x0c ? x0c + s.PS : nullptr));
+    CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PSb : nullptr, x0c ? x0c + s.PSb : nullptr));
     e = gp();
     e.epi = EPI_UPDATE; e.C[0] = hc; e.bias = w.bu; e.hsrc = Z; e.hsrc_ld = s.Cp; e.zr = zr;
     e.out2 = hnext; e.out2_ld = hnext_ld; e.H = s.H;
@@ -685,7 +703,7 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     const long long RH = s.R * s.H;
     bool xu = false, xg = false;
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PS : nullptr));
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg, dPb));
     if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
@@ -905,7 +923,7 @@ struct ModelPlan {
     // MCRN_BF16: stacked bf16 adjacency and its transpose, T2 matrices, per-call bf16 operands, adjacency-gradient blocks
     bool bf16;
     int nb, Kp;
-    uint16_t *Sstk, *STstk, *bfzero;
+    uint16_t *Sstk, *STstk, *sqb;   // sqb: one zero-padded bf16 [Kp][Kp] matrix (S for the T2 product, dT in the backward pass)
     float *T2[2], *dA, *mu, *mu_part;
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     size_t total;
@@ -929,7 +947,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.bf16 = d->precision == MCRN_BF16;
     P.se = mk_shape(B, N, d->input_dim, H, K, P.bf16);
     P.sd = mk_shape(B, N, od + yd, Hd, K, P.bf16);
-    P.ldS = (N + 3) & ~3;
+    P.ldS = d->precision == MCRN_BF16 ? (N + 7) & ~7 : (N + 3) & ~3;
     P.nslabS = nslab_S(N);
     plan_sup(b, N, M, D, P.ldS, P.sup);
     P.defer_ds = false; P.ndef_d = P.ndef_e = 0;
@@ -992,23 +1010,23 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.nb = 2 * (K - 1); P.Kp = (N + 63) & ~63;
-    P.Sstk = P.STstk = P.bfzero = nullptr; P.T2[0] = P.T2[1] = P.dA = P.mu = P.mu_part = nullptr;
+    P.Sstk = P.STstk = P.sqb = nullptr; P.T2[0] = P.T2[1] = P.dA = P.mu = P.mu_part = nullptr;
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
     if (P.bf16) {
-        P.bfzero = b.take<uint16_t>(128);
         P.Sstk = b.take<uint16_t>((size_t)P.nb * N * P.Kp);
         P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
+        P.sqb = b.take<uint16_t>((size_t)P.Kp * P.Kp);
         for (int i = 0; i < 2; ++i) P.T2[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;
         P.dA = b.take<float>((size_t)P.nb * N * P.ldS);
         const long long ldm = P.se.ld > P.sd.ld ? P.se.ld : P.sd.ld;
         P.mu = b.take<float>((size_t)ldm);
         P.mu_part = b.take<float>(colsum_part_floats(N, (int)ldm, MU_CHUNK) + 1024);
-        P.x0b_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PS);
-        P.x0c_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PS);
-        P.x0b_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PS);
-        P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PS);
-        P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PS);
-        P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PS);
+        P.x0b_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
+        P.x0c_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
+        P.x0b_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
+        P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
+        P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PSb);
+        P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PSb);
     }
     P.total = (b.off + 255) & ~(size_t)255;
 }
@@ -1024,63 +1042,69 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
     u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
     u.defer = false;
-    u.Sstk = P.Sstk; u.STstk = P.STstk; u.zero = P.bfzero; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
+    u.Sstk = P.Sstk; u.STstk = P.STstk; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
     return u;
 }
 
-// MCRN_BF16, once per forward: T2(S) = 2 S S - I (model/MegaCRN.py:20-22), then the stacked bf16 operands
-static int build_stacks(const ModelPlan& P, int N, int K, hipStream_t st) {
-    CK(hipMemsetAsync(P.bfzero, 0, 256, st));
-    const float* blk[4];
-    int nblk = 0;
+// MCRN_BF16, once per forward: the stacked bf16 operands.  T2(S) = 2 S S - I (model/MegaCRN.py:20-22) is itself a
+// bf16-resident product: A = the S block of the stack just built (rows, K-contiguous), B = the same block read as [k][n].
+static int build_stacks(const ModelPlan& P, const Sup& u, int N, int K, hipStream_t st) {
+    const int nb = P.nb;
+    const dim3 g(cdiv(P.Kp, 32), cdiv(N, 32));
+    auto put = [&](const float* M_, int blk) -> int {
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 0, P.Sstk, (long long)P.Kp, (long long)blk * N, 0LL);
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 1, P.STstk, (long long)nb * P.Kp, 0LL, (long long)blk * P.Kp);
+        return 0;
+    };
     for (int sidx = 0; sidx < 2; ++sidx) {
         const float* S = sidx ? P.sup.g2 : P.sup.g1;
-        blk[nblk++] = S;
+        const int blk = sidx * (K - 1);
+        CKI(put(S, blk));
         if (K == 3) {
-            GemmP q = gp();
-            q.M = N; q.N = N; q.K = N;
-            q.A[0] = S; q.am = plain(P.ldS); q.ak = plain(1);
-            q.B[0] = S; q.bk = plain(P.ldS); q.bn = plain(1);
-            q.C[0] = P.T2[sidx]; q.cm = plain(P.ldS); q.cn = plain(1);
-            q.alpha = 2.f;
-            CKI(gemm(q, true, false, 0, ROLE_MISC, st));
+            // S as a zero-padded [Kp][Kp] bf16 matrix: the [k][n] operand must be finite for k up to Kp
+            Shp t; t.N = N; t.ld = P.ldS; t.PS = (long long)N * P.ldS; t.Kp = P.Kp; t.ldp = P.Kp; t.PSb = (long long)P.Kp * P.Kp;
+            CKI(planes_to_bf16(t, S, 1, P.sqb, nullptr, nullptr, st, N));
+            Bf16GemmP q = bgp(u);
+            q.A = P.sqb; q.am = rm_plain(P.Kp); q.M = N;
+            q.B = P.sqb; q.ldb = P.Kp; q.N = (N + 7) & ~7;        // columns N .. are zero padding
+            q.nseg = 1; q.seg_len = N;
+            q.C = P.T2[sidx]; q.cm = rm_plain(P.ldS); q.alpha = 2.f;
+            CKI(bf16_gemm(q, true, 1, ROLE_MISC, 0, st));
             LAUNCH(k_sub_eye, dim3(cdiv(N, 256)), dim3(256), 0, st, P.T2[sidx], P.ldS, N);
-            blk[nblk++] = P.T2[sidx];
+            CKI(put(P.T2[sidx], blk + 1));
         }
-    }
-    const dim3 g(cdiv(P.Kp, 32), cdiv(N, 32));
-    for (int b_ = 0; b_ < nblk; ++b_) {
-        LAUNCH(k_stack_build, g, dim3(256), 0, st, blk[b_], P.ldS, N, P.Kp, 0, P.Sstk, (long long)P.Kp, (long long)b_ * N, 0LL);
-        LAUNCH(k_stack_build, g, dim3(256), 0, st, blk[b_], P.ldS, N, P.Kp, 1, P.STstk, (long long)nblk * P.Kp, 0LL,
-               (long long)b_ * P.Kp);
     }
     return 0;
 }
 // MCRN_BF16, once per backward: chain rule of T2 = 2 S S - I onto S, in place in the S blocks of dA
-//   dS = dA[S] + 2 (dT S^T + S^T dT),  dT = dA[T2]
-static int t2_backward(const ModelPlan& P, int N, int K, hipStream_t st) {
+//   dS = dA[S] + 2 (dT S^T + S^T dT),  dT = dA[T2]   - two bf16-resident products per support
+static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream_t st) {
     if (K != 3) return 0;
     for (int sidx = 0; sidx < 2; ++sidx) {
-        const float* S = sidx ? P.sup.g2 : P.sup.g1;
         float* dS = P.dA + (long long)(2 * sidx) * N * P.ldS;
         const float* dT = P.dA + (long long)(2 * sidx + 1) * N * P.ldS;
-        {   // dS += 2 dT S^T
-            GemmP q = gp();
-            q.M = N; q.N = N; q.K = N;
-            q.A[0] = dT; q.am = plain(P.ldS); q.ak = plain(1);
-            q.B[0] = S; q.bk = plain(1); q.bn = plain(P.ldS);
-            q.C[0] = dS; q.Cin[0] = dS; q.cm = plain(P.ldS); q.cn = plain(1);
-            q.alpha = 2.f; q.beta = 1.f;
-            CKI(gemm(q, true, true, 0, ROLE_MISC, st));
+        uint16_t* dTb = P.sqb;              // dT as a zero-padded bf16 [Kp][Kp] matrix (rows K-contiguous / [k][n])
+        {
+            Shp t; t.N = N; t.ld = P.ldS; t.PS = (long long)N * P.ldS; t.Kp = P.Kp; t.ldp = P.Kp; t.PSb = (long long)P.Kp * P.Kp;
+            CKI(planes_to_bf16(t, dT, 1, dTb, nullptr, nullptr, st, N));
         }
-        {   // dS += 2 S^T dT
-            GemmP q = gp();
-            q.M = N; q.N = N; q.K = N;
-            q.A[0] = S; q.am = plain(1); q.ak = plain(P.ldS);
-            q.B[0] = dT; q.bk = plain(P.ldS); q.bn = plain(1);
-            q.C[0] = dS; q.Cin[0] = dS; q.cm = plain(P.ldS); q.cn = plain(1);
-            q.alpha = 2.f; q.beta = 1.f;
-            CKI(gemm(q, false, false, 0, ROLE_MISC, st));
+        const uint16_t* Sb = P.Sstk + (long long)(2 * sidx) * N * P.Kp;          // S rows
+        const uint16_t* STb = P.STstk + (long long)(2 * sidx) * P.Kp;            // S^T rows (row stride nb*Kp)
+        {   // dS += 2 dT S^T :  B(k, n) = S[n][k]  ->  NT with B = S rows
+            Bf16GemmP q = bgp(u);
+            q.A = dTb; q.am = rm_plain(P.Kp); q.M = N;
+            q.B = Sb; q.bm = rm_plain(P.Kp); q.N = N;
+            q.nseg = 1; q.seg_len = N;
+            q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
+            CKI(bf16_gemm(q, false, 1, ROLE_MISC, 0, st));
+        }
+        {   // dS += 2 S^T dT :  A = S^T rows, B = dT as [k][n]
+            Bf16GemmP q = bgp(u);
+            q.A = STb; q.am = rm_plain((long long)P.nb * P.Kp); q.M = N;
+            q.B = dTb; q.ldb = P.Kp; q.N = (N + 7) & ~7;
+            q.nseg = 1; q.seg_len = N;
+            q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
+            CKI(bf16_gemm(q, true, 1, ROLE_MISC, 0, st));
         }
     }
     return 0;
@@ -1186,8 +1210,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
     CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
-    if (P.bf16) CKI(build_stacks(P, N, d->cheb_k, st));
     Sup u = model_sup(P, N);
+    if (P.bf16) CKI(build_stacks(P, u, N, d->cheb_k, st));
     const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], st, P.imgf[i], P.imgd[i]));
@@ -1200,8 +1224,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     for (int t = 0; t < Ti; ++t)
         CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
-                          we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PS : nullptr,
-                          P.bf16 ? P.x0c_e + (long long)2 * t * se.PS : nullptr));
+                          we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PSb : nullptr,
+                          P.bf16 ? P.x0c_e + (long long)2 * t * se.PSb : nullptr));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
                           P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
@@ -1218,8 +1242,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
         CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
-                          P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PS : nullptr,
-                          P.bf16 ? P.x0c_d + (long long)2 * t * sd.PS : nullptr));
+                          P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PSb : nullptr,
+                          P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr));
         const bool last = t + 1 == To;
         const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;
         LAUNCH(k_proj_fwd, dim3(cdiv(R, 4) < 2048 ? cdiv(R, 4) : 2048), dim3(256), 0, st, (const float*)Zn,
@@ -1291,7 +1315,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
                               P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PS : nullptr));
+                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PSb : nullptr));
             dPprev = dPt; dQprev = dQt;
         }
     }
@@ -1348,7 +1372,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
                               P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PS : nullptr));
+                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PSb : nullptr));
         }
     }
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
@@ -1364,7 +1388,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
         CKI(ds_bf16(sd, u, P.dPb_d, P.x0c_d, 2 * To, P.dA, P.ldS, false, st));
         CKI(ds_bf16(se, u, P.dPb_e, P.x0c_e, 2 * Ti, P.dA, P.ldS, true, st));
-        CKI(t2_backward(P, N, d->cheb_k, st));
+        CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
                          P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st));
     } else

@@ -1,28 +1,32 @@
 // gemm_bf16.h - plain-bf16 GEMM for gfx950 (MI355X): bf16-RESIDENT operands, one v_mfma_f32_32x32x16_bf16 per
-// product, fp32 accumulate.  This is the MCRN_BF16 arithmetic of the large-graph path (N >= 512): the K-hop
-// propagation  [S1; T2(S1); S2; T2(S2)] x X  (model/MegaCRN.py:20-25), its transpose in the backward pass and the
-// adjacency gradient  dP x X^T.  (bf16x3 - gemm_bf16x3.h - stays the 1e-4 parity arithmetic)
+// product, fp32 accumulate.  This is the MCRN_BF16 arithmetic of the large-graph path: the K-hop propagation
+// [S1; T2(S1); S2; T2(S2)] x X  (model/MegaCRN.py:20-25), its transpose in the backward pass and the adjacency
+// gradient  dP x X^T.  (bf16x3 - gemm_bf16x3.h - stays the 1e-4 parity arithmetic)
 //
 //   C[m][n] = alpha * sum_k A[m][k] * B(k, n)  (+ beta * Cin[m][n])
 //
-// A is always K-contiguous (row m = 64-element runs of k).  B comes in two storage forms:
-//   BTR = false ("NT"): B stored [n][k], K-contiguous like A                     (adjacency gradient: both operands
-//                       are node-major planes, contracted over their columns)
-//   BTR = true  ("NN"): B stored [k][n], n contiguous                            (propagation: B = a plane, k = node)
-//                       -> the MFMA B fragment (8 consecutive k per lane) is produced by ds_read_b64_tr_b16, the
-//                       LDS transpose read of gfx950, from an image of [4 k][16 n] blocks.
-// Operand tiles travel HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, 16 B per lane, no VGPR round trip):
-// the LDS destination of a wave instruction is linear (base + 16*lane), so every layout below is expressed by
-// WHICH 16-byte chunk a lane fetches (per-lane source address), never by a scattered destination.
-//   * K-contiguous tiles (BM x 64 k, 128-byte rows): chunk (row, c) sits in slot  (row>>1)*16 + ((8*(row&1)+c) ^
-//     ((row>>1)&15)) - a 16-slot XOR swizzle over row pairs, conflict-free for the ds_read_b128 lane groups.
-//   * [k][n] tiles (64 k x BN n): 128-byte blocks of [4 k][16 n], blocks ordered [k/4][n/16]; the two 16-lane
-//     groups of a half wave read two adjacent blocks = one full 256-byte bank row.
-//   * rows / columns / k beyond the operand, and tail chunks, are fetched from a 16-byte ZERO PAGE instead of being
-//     predicated: every lane always issues its load, no divergent control flow in the K loop.
+// A is always K-contiguous (row m = runs of k).  B comes in two storage forms:
+//   BTR = false ("NT"): B stored [n][k], K-contiguous like A     (adjacency gradient: both operands are node-major
+//                       planes, contracted over their columns)
+//   BTR = true  ("NN"): B stored [k][n], n contiguous            (propagation: B = a plane, k = node)
+//                       -> the MFMA B fragment (8 consecutive k per lane) is produced by ds_read_b64_tr_b16, the LDS
+//                       transpose read of gfx950, from an image of [4 k][16 n] blocks.
+// OPERAND CONTRACT (what lets the K loop run without a single predicate or per-lane address update):
+//   * K-contiguous operands are readable and ZERO from seg_len up to the next multiple of 64 in every segment
+//     (the stacked adjacency is built that way; bf16 planes carry zero pad columns);
+//   * [k][n] operands are readable and FINITE for k up to the next multiple of 64 of seg_len (zero pad rows);
+//   * rows m >= M / columns n >= N are CLAMPED to the last valid one when fetched (their products are never stored).
+// Operand tiles travel L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, 16 B per lane, no VGPR round trip), in the
+// SGPR-base + 32-bit lane-offset form: the lane offsets are constants of the thread, a tile costs a handful of SALU
+// instructions.  The LDS destination of a wave instruction is linear (base + 16*lane), so every layout is expressed by
+// WHICH 16-byte chunk a lane fetches:
+//   * K-contiguous tiles (rows of CH = BK/8 chunks, RP = 16/CH rows per 256-byte bank row): chunk (row, c) sits in
+//     slot  Q*16 + ((CH*(row % RP) + c) ^ (Q & 15)),  Q = row / RP   - conflict-free for the ds_read_b128 lane groups
+//     (SQ_LDS_BANK_CONFLICT = 0, profiles/r2);
+//   * [k][n] tiles: 128-byte blocks of [4 k][16 n], blocks ordered [k/4][n/16]; the two 16-lane groups of a half
+//     wave read two adjacent blocks = one full 256-byte bank row.
 // K is a list of equal segments (k-tile kt -> segment kt / tps): one segment = one Chebyshev block of the stacked
-// transposed adjacency (backward propagation) or one time step (deferred adjacency gradient).
-// Pipeline: 2 LDS stages; the loads of tile t+1 are issued before the MFMA block of tile t, one barrier per tile.
+// transposed adjacency (backward propagation) or one AGCN call (deferred adjacency gradient).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,188 +38,156 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16*lane] = *gsrc.  Issued from inline asm ON PURPOSE: hipcc treats the
-// builtin form as a pending LDS write that may alias every later ds_read and drains it (s_waitcnt vmcnt(0)) in
-// front of the MFMA block it was meant to overlap.  The asm form is invisible to that bookkeeping; the K loop
-// waits for it itself (one s_waitcnt vmcnt(0) in front of the barrier that publishes the tile).  M0 carries the
-// wave-uniform LDS address and is compiler-reserved: saved and restored inside the same statement.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16*lane] = *(sbase + voff).  Issued from inline asm ON PURPOSE: hipcc
+// treats the builtin form as a pending LDS write that may alias every later ds_read and drains it (s_waitcnt vmcnt(0))
+// in front of the MFMA block it was meant to overlap.  The asm form is invisible to that bookkeeping; the K loops
+// below count it themselves (s_waitcnt vmcnt(N)).  M0 carries the wave-uniform LDS address and is compiler-reserved:
+// saved and restored inside the same statement.
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+#define MCRN_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-// One workgroup = WGM x WGN waves, wave tile (BM/WGM) x (BN/WGN) built from 32x32 fragments, BK = 64.
-template <int BM, int BN, int WGM, int WGN, bool BTR>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16GemmP p) {
-    constexpr int NW = WGM * WGN, NT = 64 * NW;
-    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
-    constexpr int ASLOTS = BM * 8, BSLOTS = BN * 8;            // 16-byte chunks per tile
-    constexpr int AJ = ASLOTS / NT, BJ = BSLOTS / NT;          // chunks per thread
-    static_assert(ASLOTS % NT == 0 && BSLOTS % NT == 0, "tile / workgroup mismatch");
-    constexpr int STAGE = (ASLOTS + BSLOTS) * 16;              // bytes
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];   // 2 stages
+// ---- pieces shared by the two kernels ------------------------------------------------------------------------
+template <int BM, int BN, int BK, int NT, bool BTR>
+struct Bf16Tile {
+    static constexpr int CH = BK / 8, RP = 16 / CH, KS = BK / 16;
+    static constexpr int ASLOTS = BM * CH, BSLOTS = BN * CH;            // 16-byte chunks per tile
+    static constexpr int AJ = (ASLOTS + NT - 1) / NT, BJ = (BSLOTS + NT - 1) / NT;
+    static constexpr int NLD_MIN = ASLOTS / NT + BSLOTS / NT;           // DMA instructions every wave issues per tile
+    static constexpr int STAGE = (ASLOTS + BSLOTS) * 16;                // bytes
+    static_assert(ASLOTS % 64 == 0 && BSLOTS % 64 == 0, "whole waves per pass");
+    static_assert(BK == 32 || BK == 64, "BK");
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, kq = lane >> 5;
+    unsigned offA[AJ], offB[BJ];          // byte offsets of this thread's chunks from the tile's scalar base
+    const uint16_t *baseA, *baseB;        // scalar: first element of the workgroup's rows / columns
+    long long stepA_seg, stepB_seg, stepB_k;   // scalar strides (elements)
+    int tps;
+    int iss_seg, iss_lt;                  // K tile the next DMA will fetch
 
-    // ---- tile of this workgroup
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    int tile_m, tile_n;
-    {
-        const int nblk = tiles_m * tiles_n;
-        int L = blockIdx.x;
-        if (p.xcd) {   // workgroups are dealt round-robin to the 8 XCDs: give XCD x a contiguous range of tiles (bijective)
-            const int q = nblk >> 3, r = nblk & 7, x = L & 7, i = L >> 3;
-            L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-        }
-        constexpr int GM = 4;                                   // walk GM row tiles per column tile: compact C patches
-        const int width = GM * tiles_n;
-        const int grp = L / width, first_m = grp * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        const int rr = L - grp * width;
-        tile_m = first_m + rr % gsz; tile_n = rr / gsz;
-    }
-    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int split = blockIdx.z;
-    const int nkt = p.nseg * p.tps;
-    const int kt_beg = split * p.tiles_per_split;
-    const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
-    if (kt_beg >= kt_end) return;
-
-    // ---- per-thread source description of its chunks (constant over the K loop)
-    long long offA[AJ], offB[BJ];
-    int cA[AJ], kB[BJ];                                         // A / NT-B: chunk index c (k = 8c) ; NN-B: k row inside the tile
-    bool okA[AJ], okB[BJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int s = j * NT + tid;
-        const int R = s >> 4, sw = (s & 15) ^ (R & 15);
-        const int row = 2 * R + (sw >> 3), c = sw & 7;
-        const int gr = m_blk + row;
-        okA[j] = gr < p.M;
-        cA[j] = c;
-        offA[j] = rm_off(p.am, okA[j] ? gr : 0) + 8 * c;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int s = j * NT + tid;
-        if (BTR) {
-            const int blk = s >> 3, kr = (s >> 1) & 3, half = s & 1;
-            const int kb = blk / (BN / 16), nb = blk - kb * (BN / 16);
-            const int k = 4 * kb + kr, n = n_blk + 16 * nb + 8 * half;
-            okB[j] = n < p.N;
-            kB[j] = k;
-            offB[j] = (long long)k * p.ldb + (okB[j] ? n : 0);
-        } else {
-            const int R = s >> 4, sw = (s & 15) ^ (R & 15);
-            const int row = 2 * R + (sw >> 3), c = sw & 7;
-            const int gn = n_blk + row;
-            okB[j] = gn < p.N;
-            kB[j] = c;
-            offB[j] = rm_off(p.bm, okB[j] ? gn : 0) + 8 * c;
-        }
-    }
-
-    auto stage = [&](int kt, int stg) {
-        const int seg = kt / p.tps, lt = kt - seg * p.tps;
-        const int kl0 = lt * 64;
-        const int krem = p.seg_len - kl0;                        // valid k in this tile (>= 1; < 64 only in a tail tile)
-        const uint16_t* __restrict__ Ab = p.A + (long long)seg * p.a_seg + kl0;
-        const uint16_t* __restrict__ Bb = BTR ? p.B + (long long)seg * p.b_seg + (long long)kl0 * p.ldb
-                                              : p.B + (long long)seg * p.b_seg + kl0;
-        const unsigned sA = lds_base + stg * STAGE + wave * 1024;   // this wave's 64 slots of pass j = 0
-        const unsigned sB = sA + ASLOTS * 16;
+    __device__ __forceinline__ void init(const Bf16GemmP& p, int tid, int m_blk, int n_blk, int kt_beg) {
+        const long long a0 = rm_off(p.am, m_blk);
+        baseA = p.A + a0;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const bool ok = okA[j] && 8 * cA[j] < krem;
-            const uint16_t* src = ok ? Ab + offA[j] : p.zero;
-            glds16(src, sA + j * NT * 16);
+            const int s = min(j * NT + tid, ASLOTS - 1);        // (a partial last pass is skipped by whole waves)
+            const int Q = s >> 4, sw = (s & 15) ^ (Q & 15);
+            const int row = Q * RP + sw / CH, c = sw % CH;
+            const int gr = min(m_blk + row, p.M - 1);
+            offA[j] = (unsigned)((rm_off(p.am, gr) - a0 + 8 * c) * 2);
         }
+        if (BTR) {
+            baseB = p.B + n_blk;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const bool ok = okB[j] && (BTR ? kB[j] : 8 * kB[j]) < krem;
-            const uint16_t* src = ok ? Bb + offB[j] : p.zero;
-            glds16(src, sB + j * NT * 16);
+            for (int j = 0; j < BJ; ++j) {
+                const int s = min(j * NT + tid, BSLOTS - 1);
+                const int blk = s >> 3, kr = (s >> 1) & 3, half = s & 1;
+                const int kb = blk / (BN / 16), nb = blk - kb * (BN / 16);
+                const int k = 4 * kb + kr;
+                const int n = min(n_blk + 16 * nb + 8 * half, p.N - 8);
+                offB[j] = (unsigned)(((long long)k * p.ldb + (n - n_blk)) * 2);
+            }
+            stepB_k = p.ldb;
+        } else {
+            const long long b0 = rm_off(p.bm, n_blk);
+            baseB = p.B + b0;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int s = min(j * NT + tid, BSLOTS - 1);
+                const int Q = s >> 4, sw = (s & 15) ^ (Q & 15);
+                const int row = Q * RP + sw / CH, c = sw % CH;
+                const int gn = min(n_blk + row, p.N - 1);
+                offB[j] = (unsigned)((rm_off(p.bm, gn) - b0 + 8 * c) * 2);
+            }
+            stepB_k = 1;
         }
-    };
+        stepA_seg = p.a_seg; stepB_seg = p.b_seg; tps = p.tps;
+        iss_seg = kt_beg / p.tps; iss_lt = kt_beg - iss_seg * p.tps;
+    }
+    // DMA of the next K tile into LDS stage `stg`
+    __device__ __forceinline__ void issue(unsigned lds_base, int stg, int wave) {
+        const uint16_t* __restrict__ Ab = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
+        const uint16_t* __restrict__ Bb = baseB + (long long)iss_seg * stepB_seg + (long long)(iss_lt * BK) * stepB_k;
+        const unsigned sA = lds_base + stg * STAGE + wave * 1024;
+        const unsigned sB = sA + ASLOTS * 16;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            if (ASLOTS % NT == 0 || j * NT + wave * 64 < ASLOTS) glds16(Ab, offA[j], sA + j * NT * 16);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(Bb, offB[j], sB + j * NT * 16);
+        if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; }
+    }
+};
 
-    // ---- fragment read addresses (bytes inside a stage's A / B image)
-    int a0, b0;
-    {
-        const int row = wm * WM + l31;                           // fragment i adds 32 rows = 16 row pairs: same XOR key
-        const int R = row >> 1, q = R & 15;
-        a0 = R * 256 + (((8 * (row & 1) + kq) ^ q) << 4);
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); XCD x gets a contiguous
+// range of tiles (bijective for any tile count), walked GM row tiles per column tile: the tiles resident on one XCD
+// cover a compact patch of C and share A row panels / B column panels in its L2.
+__device__ __forceinline__ void bf16_tile_of(const Bf16GemmP& p, int BM, int BN, int& tile_m, int& tile_n) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = tiles_m * tiles_n;
+    int L = blockIdx.x;
+    if (p.xcd) {
+        const int q = nblk >> 3, r = nblk & 7, x = L & 7, i = L >> 3;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    constexpr int GM = 4;
+    const int width = GM * tiles_n;
+    const int grp = L / width, first_m = grp * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int rr = L - grp * width;
+    tile_m = first_m + rr % gsz; tile_n = rr / gsz;
+}
+
+template <int FM, int FN, int BN, int CH, int RP, bool BTR>
+__device__ __forceinline__ void bf16_frag_offsets(int row_a0, int row_b0, int lane, int (&aoff)[FM], int (&boff)[FN]) {
+    const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = row_a0 + i * 32 + l31;
+        const int Q = row / RP;
+        aoff[i] = Q * 256 + (((CH * (row % RP) + kq) ^ (Q & 15)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
         if (BTR) {
             const int g = lane >> 4, i = lane & 15;
             const int kq2 = g >> 1, nhalf = g & 1;
-            b0 = ((2 * kq2) * (BN / 16) + (wn * WN) / 16 + nhalf) * 128 + (i >> 2) * 32 + (i & 3) * 8;
+            boff[j] = ((2 * kq2) * (BN / 16) + row_b0 / 16 + 2 * j + nhalf) * 128 + (i >> 2) * 32 + (i & 3) * 8;
         } else {
-            const int rowb = wn * WN + l31;
-            const int Rb = rowb >> 1, qb = Rb & 15;
-            b0 = Rb * 256 + (((8 * (rowb & 1) + kq) ^ qb) << 4);
+            const int row = row_b0 + j * 32 + l31;
+            const int Q = row / RP;
+            boff[j] = Q * 256 + (((CH * (row % RP) + kq) ^ (Q & 15)) << 4);
         }
     }
-
-    f32x16_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    stage(kt_beg, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's part of the tile has landed ...
-    __syncthreads();                                             // ... and so has everybody else's
-    int cur = 0;
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);             // in flight during the MFMA block below
-        const unsigned char* sA = smem_bf16 + cur * STAGE;
-        const unsigned char* sB = sA + ASLOTS * 16;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t a[FM], b[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ((a0 ^ (ks << 5)) + i * 4096));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if (BTR) {
-                    const unsigned char* q = sB + b0 + (4 * ks) * (BN / 16) * 128 + 2 * j * 128;
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(q));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(q + (BN / 16) * 128));
-                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-                    const s16x8_t w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    b[j] = __builtin_bit_cast(bf16x8_t, w);
-                } else {
-                    b[j] = *reinterpret_cast<const bf16x8_t*>(sB + ((b0 ^ (ks << 5)) + j * 4096));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile kt+1: this wave's LDS-DMA has landed
-        __syncthreads();                                         // tile kt consumed by every wave, tile kt+1 visible to all
-        cur ^= 1;
+}
+template <int BN, bool BTR>
+__device__ __forceinline__ bf16x8_t bf16_read_b(const unsigned char* sB, int boff, int ks) {
+    if (BTR) {
+        const unsigned char* q = sB + boff + (4 * ks) * (BN / 16) * 128;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + (BN / 16) * 128));
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+        const s16x8_t w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, w);
     }
+    return *reinterpret_cast<const bf16x8_t*>(sB + (boff ^ (ks << 5)));
+}
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+// epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+template <int FM, int FN>
+__device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int split, int r_base, int c_base,
+                                              int lane) {
+    const int l31 = lane & 31, kq = lane >> 5;
     float* __restrict__ C = p.C ? p.C + (long long)split * p.slab : nullptr;
-    const float* __restrict__ Cin = p.Cin ? p.Cin + (long long)split * p.slab : nullptr;
+    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + (long long)split * p.slab : nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int r0 = m_blk + wm * WM + i * 32 + 4 * kq;
+        const int r0 = r_base + i * 32 + 4 * kq;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int r = r0 + (v & 3) + 8 * (v >> 2);
@@ -224,7 +196,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
             const long long rob = p.Cb ? rm_off(p.cbm, r) : 0;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int c = n_blk + wn * WN + j * 32 + l31;
+                const int c = c_base + j * 32 + l31;
                 if (c >= p.N) continue;
                 float o = p.alpha * acc[i][j][v];
                 if (Cin) o += p.beta * Cin[ro + c];
@@ -239,46 +211,378 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     }
 }
 
-// ---- host side ----------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 1: every wave does the same thing.  NSTAGE LDS stages form a ring; per K tile:
+//     wait(tile t landed for this wave) ; barrier (landed for everybody, tile t-1 consumed by everybody) ;
+//     multiply tile t, fragment reads and MFMAs interleaved by the compiler ; issue the DMA of tile t+NSTAGE-1 into the
+//     stage tile t-1 just left (after the MFMAs in program order: they run while the addresses are formed).
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16GemmP p) {
+    constexpr int NW = WGM * WGN, NT = 64 * NW;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
 
-template <int BM, int BN, int WGM, int WGN, bool BTR>
-static inline hipError_t launch_one_bf16(const Bf16GemmP& p, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr size_t lds = 2 * (BM * 8 + BN * 8) * 16;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
+    const int wm = wave / WGN, wn = wave % WGN;
+    int tile_m, tile_n;
+    bf16_tile_of(p, BM, BN, tile_m, tile_n);
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int split = blockIdx.z;
+    const int nkt = p.nseg * p.tps;
+    const int kt_beg = split * p.tiles_per_split;
+    const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
+    if (kt_beg >= kt_end) return;
+    const int nt = kt_end - kt_beg;
+
+    T tl;
+    tl.init(p, tid, m_blk, n_blk, kt_beg);
+    int aoff[FM], boff[FN];
+    bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nt) tl.issue(lds_base, s, wave);
+    int rd = 0;
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed once at most the DMA of the NSTAGE-2 younger tiles remains in flight (steady state);
+        // in the tail fewer tiles are in flight: drain
+        if (NSTAGE > 2 && t + NSTAGE - 2 < nt) MCRN_VMCNT((NSTAGE - 2) * T::NLD_MIN);
+        else MCRN_VMCNT(0);
+        __syncthreads();                                         // tile t visible to all; tile t-1 consumed by all
+        const unsigned char* sA = smem_bf16 + rd * T::STAGE;
+        const unsigned char* sB = sA + T::ASLOTS * 16;
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+            bf16x8_t a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + NSTAGE - 1 < nt) {
+            int wr = rd + NSTAGE - 1;
+            if (wr >= NSTAGE) wr -= NSTAGE;
+            tl.issue(lds_base, wr, wave);                        // refill the stage tile t-1 left (all waves passed the barrier)
+        }
+        if (++rd == NSTAGE) rd = 0;
     }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BTR>), dim3(tiles, 1, p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
-    return hipGetLastError();
+    bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
-template <bool BTR>
-static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, hipStream_t st) {
-    switch (cfg) {
-        case 0: return launch_one_bf16<128, 128, 2, 2, BTR>(p, st);
-        case 1: return launch_one_bf16<256, 128, 4, 2, BTR>(p, st);
-        case 2: return launch_one_bf16<128, 256, 2, 4, BTR>(p, st);
-        default: return launch_one_bf16<256, 256, 2, 4, BTR>(p, st);
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 2, ping-pong (8 waves = two groups of four, one wave of each group per SIMD).  The K loop is a sequence of
+// barrier-separated PHASES; a group alternates a LOAD phase (all fragments of a K tile: LDS -> registers) with a
+// COMPUTE phase (back-to-back MFMAs from registers), and group 1 runs one phase behind group 0: whenever one wave of
+// a SIMD feeds the matrix pipe, its partner uses the LDS and issues the DMA of a later tile.
+//     phase 2t   : G0 load(t)    | G1 compute(t-1)      every wave issues the DMA of tile t+NSTAGE-1 (its stage was
+//     phase 2t+1 : G0 compute(t) | G1 load(t)           released by the barrier that ended phase 2t-1)
+// and waits (counted vmcnt) for its share of tile t+1 before the barrier that ends phase 2t+1.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
+    constexpr int WGM = 2, WGN = 4, NT = 512;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+    static_assert(BM % 64 == 0 && BN % 128 == 0, "tile shape");
+    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
+    constexpr int KS = T::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int grp = wm;                                          // waves 0-3: group 0 (upper half of the tile), 4-7: group 1
+    int tile_m, tile_n;
+    bf16_tile_of(p, BM, BN, tile_m, tile_n);
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int split = blockIdx.z;
+    const int nkt = p.nseg * p.tps;
+    const int kt_beg = split * p.tiles_per_split;
+    const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
+    if (kt_beg >= kt_end) return;
+    const int nt = kt_end - kt_beg;
+
+    T tl;
+    tl.init(p, tid, m_blk, n_blk, kt_beg);
+    int aoff[FM], boff[FN];
+    bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    bf16x8_t fa[FM][KS], fb[FN][KS];
+    auto load_frags = [&](int stg) {
+        const unsigned char* sA = smem_bf16 + stg * T::STAGE;
+        const unsigned char* sB = sA + T::ASLOTS * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i][ks] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j][ks] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+        }
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // wait until this wave's share of tile u has landed: issued so far are tiles <= u + NSTAGE - 2
+    auto wait_landed = [&](int u) {
+        if (NSTAGE > 2 && u + NSTAGE - 2 < nt) MCRN_VMCNT((NSTAGE - 2) * T::NLD_MIN);
+        else MCRN_VMCNT(0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nt) tl.issue(lds_base, s, wave);
+    wait_landed(0);
+    __syncthreads();
+    int rd = 0, wr = NSTAGE - 1;                                 // stage read next / stage the next DMA fills
+    if (grp == 0) {
+        for (int t = 0; t < nt; ++t) {
+            load_frags(rd);                                      // phase 2t
+            if (t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            compute();                                           // phase 2t+1
+            if (t + 1 < nt) wait_landed(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (++rd == NSTAGE) rd = 0;
+        }
+    } else {
+        if (NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }   // phase 0: nothing to compute yet
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            load_frags(rd);                                      // phase 2t+1
+            if (t + 1 < nt) wait_landed(t + 1);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            compute();                                           // phase 2t+2
+            if (t + NSTAGE < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nt) __syncthreads();
+            if (++rd == NSTAGE) rd = 0;
+        }
     }
+    bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
-// fills the derived fields (tps, split ranges) and launches
-hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st) {
-    if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.seg_len <= 0) return hipSuccess;
-    // NT: whole 16-byte chunks of k.  NN: whole chunks of n; A rows must be readable (and zero) up to the next multiple
-    // of 8 beyond seg_len (the stacked adjacency is stored with rows padded to a multiple of 64).
-    if ((!btr && (p.seg_len & 7)) || (btr && (p.N & 7)) || !p.zero) return hipErrorInvalidValue;
-    p.tps = (p.seg_len + 63) / 64;
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 3: FOUR waves, one per SIMD, wave tile (BM/2) x (BN/2) - up to 128 x 128 = 16 accumulator fragments in the
+// 512-register file of a lone wave.  Register blocking is what lowers the LDS traffic per MFMA (8 fragment reads feed 16
+// MFMAs; the 8-wave kernels above read 6 for 8) - with 256 x 256 tiles the LDS, not the matrix pipe, bounds those.
+// There is no partner wave to hide behind, so the wave pipelines itself:
+//   * fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of k-step s issue;
+//   * ONE barrier per 64-deep K tile, placed after the MFMAs of k-step 2: by then every wave has read the whole tile
+//     (k-step 3 is already in registers), so the barrier both publishes tile t+1 (its DMA was waited for just before)
+//     and releases tile t's stage; the DMA of tile t+2 and the first fragments of tile t+1 follow during k-step 3;
+//   * the 16 LDS-DMA instructions of a tile are interleaved with k-step 3's MFMAs in groups of four.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool BTR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(const Bf16GemmP p) {
+    constexpr int BK = 64, NT = 256, NSTAGE = 2;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
+    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
+    static_assert(T::ASLOTS % NT == 0 && T::BSLOTS % NT == 0, "tile / workgroup mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    bf16_tile_of(p, BM, BN, tile_m, tile_n);
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int split = blockIdx.z;
+    const int nkt = p.nseg * p.tps;
+    const int kt_beg = split * p.tiles_per_split;
+    const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
+    if (kt_beg >= kt_end) return;
+    const int nt = kt_end - kt_beg;
+
+    T tl;
+    tl.init(p, tid, m_blk, n_blk, kt_beg);
+    int aoff[FM], boff[FN];
+    bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    bf16x8_t fa[2][FM], fb[2][FN];
+#define MCRN_W4_READ(BUF, STG, KS_)                                                                     \
+    do {                                                                                                \
+        const unsigned char* sA_ = smem_bf16 + (STG) * T::STAGE;                                        \
+        const unsigned char* sB_ = sA_ + T::ASLOTS * 16;                                                \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                 \
+            fa[BUF][i] = *reinterpret_cast<const bf16x8_t*>(sA_ + (aoff[i] ^ ((KS_) << 5)));            \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[BUF][j] = bf16_read_b<BN, BTR>(sB_, boff[j], KS_); \
+    } while (0)
+#define MCRN_W4_MMA(BUF)                                                                                \
+    do {                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[BUF][i], fb[BUF][j], acc[i][j], 0, 0, 0); \
+    } while (0)
+
+    tl.issue(lds_base, 0, wave);
+    if (nt > 1) tl.issue(lds_base, 1, wave);
+    if (nt > 1) MCRN_VMCNT(T::NLD_MIN); else MCRN_VMCNT(0);     // tile 0 landed (tile 1 may still fly)
+    __syncthreads();
+    MCRN_W4_READ(0, 0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int stg = t & 1;
+        MCRN_W4_READ(1, stg, 1);
+        MCRN_W4_MMA(0);
+        MCRN_W4_READ(0, stg, 2);
+        MCRN_W4_MMA(1);
+        MCRN_W4_READ(1, stg, 3);
+        MCRN_W4_MMA(0);
+        // every fragment of tile t is in registers; tile t+1 (this wave's share) has landed once nothing is in flight
+        MCRN_VMCNT(0);
+        __syncthreads();                                         // tile t+1 visible to all, stage of tile t free
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) MCRN_W4_READ(0, stg ^ 1, 0);
+        if (t + 2 < nt) {                                        // DMA of tile t+2 into tile t's stage, between the MFMAs
+            const uint16_t* __restrict__ Ab = tl.baseA + (long long)tl.iss_seg * tl.stepA_seg + tl.iss_lt * BK;
+            const uint16_t* __restrict__ Bb = tl.baseB + (long long)tl.iss_seg * tl.stepB_seg + (long long)(tl.iss_lt * BK) * tl.stepB_k;
+            const unsigned sA = lds_base + stg * T::STAGE + wave * 1024;
+            const unsigned sB = sA + T::ASLOTS * 16;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = i * T::AJ / FM; j < (i + 1) * T::AJ / FM; ++j) glds16(Ab, tl.offA[j], sA + j * NT * 16);
+#pragma unroll
+                for (int j = i * T::BJ / FM; j < (i + 1) * T::BJ / FM; ++j) glds16(Bb, tl.offB[j], sB + j * NT * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++tl.iss_lt == tl.tps) { tl.iss_lt = 0; ++tl.iss_seg; }
+        } else {
+            MCRN_W4_MMA(1);
+        }
+    }
+#undef MCRN_W4_READ
+#undef MCRN_W4_MMA
+    bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
+    p.tps = (p.seg_len + BK - 1) / BK;
     const int nkt = p.nseg * p.tps;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nkt) nsplit = nkt;
     p.tiles_per_split = (nkt + nsplit - 1) / nsplit;
     p.nsplit = (nkt + p.tiles_per_split - 1) / p.tiles_per_split;
-    return btr ? launch_cfg_bf16<true>(p, cfg, st) : launch_cfg_bf16<false>(p, cfg, st);
 }
-
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR>
+static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st) {
+    bf16_split_plan(p, BK, nsplit);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR>), dim3(tiles, 1, p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
+    return hipGetLastError();
+}
+template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t st) {
+    bf16_split_plan(p, BK, nsplit);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+template <int BM, int BN, bool BTR>
+static inline hipError_t launch_one_bf16_w4(Bf16GemmP p, int nsplit, hipStream_t st) {
+    bf16_split_plan(p, 64, nsplit);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<BM, BN, BTR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((gemm_bf16_w4_kernel<BM, BN, BTR>), dim3(tiles, 1, p.nsplit), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+template <bool BTR>
+static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
+    switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
+        case 0: return launch_one_bf16<128, 128, 2, 2, 64, 2, BTR>(p, nsplit, st);   //  64 KB   2
+        case 1: return launch_one_bf16<256, 128, 4, 2, 64, 3, BTR>(p, nsplit, st);   // 144 KB   1
+        case 2: return launch_one_bf16<256, 256, 2, 4, 64, 2, BTR>(p, nsplit, st);   // 128 KB   1
+        case 3: return launch_one_bf16_pp<256, 256, 32, 4, BTR>(p, nsplit, st);      // 128 KB   1   ping-pong
+        case 4: return launch_one_bf16_pp<256, 256, 64, 2, BTR>(p, nsplit, st);      // 128 KB   1   ping-pong, 64-deep phases
+        case 5: return launch_one_bf16_pp<320, 256, 32, 4, BTR>(p, nsplit, st);      // 144 KB   1   ping-pong
+        case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR>(p, nsplit, st);      // 112 KB   1   ping-pong
+        case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 8: return launch_one_bf16_w4<256, 256, BTR>(p, nsplit, st);             // 128 KB   1   4 waves, 128 x 128 each
+        case 9: return launch_one_bf16_w4<256, 128, BTR>(p, nsplit, st);             //  96 KB   1   4 waves, 128 x 64 each
+        default: return launch_one_bf16_w4<192, 256, BTR>(p, nsplit, st);            // 112 KB   1   4 waves, 96 x 128 each
+    }
+}
+hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.seg_len <= 0) return hipSuccess;
+    if (btr && ((p.N & 7) || p.N < 8)) return hipErrorInvalidValue;     // [k][n] operands are fetched in 8-column chunks
+    return btr ? launch_cfg_bf16<true>(p, cfg, nsplit, st) : launch_cfg_bf16<false>(p, cfg, nsplit, st);
+}
 
 }  // namespace mcrn

@@ -18,30 +18,33 @@ __host__ __device__ __forceinline__ long long rm_off(const RowMap& m, int r) {
     return (long long)q * m.hi + (long long)(r - q * m.inner) * m.lo;
 }
 
+// Operand contract (gemm_bf16.h): K-contiguous operands are readable and ZERO from seg_len to the next multiple of 64
+// in every segment; [k][n] operands are readable and finite for k up to the next multiple of 64 of seg_len.
 struct Bf16GemmP {
     const uint16_t* A;        // bf16 bits
     const uint16_t* B;
     RowMap am;                // A row m -> element offset of (m, k = 0) inside a segment
     RowMap bm;                // NT: B row n -> element offset ; NN: unused
     long long ldb;            // NN: elements between consecutive k rows of B
-    int nseg, seg_len, tps;   // K segments, valid k per segment (multiple of 8), k-tiles per segment = ceil(seg_len/64)
+    int nseg, seg_len, tps;   // K segments, valid k per segment, k-tiles per segment = ceil(seg_len / BK) (set by the launcher)
     long long a_seg, b_seg;   // element offset between segments
     int M, N;                 // valid rows of A ; valid columns (NT: rows of B; NN: multiple of 8)
     float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
     const float* Cin;         // nullable
+    int cin_first_only;       // split-K: only split 0 adds Cin (the other splits write plain partial results)
     RowMap cm;                // C row m -> element offset, columns contiguous
     float alpha, beta;
     int nsplit, tiles_per_split;   // split-K over k-tiles ; C / Cin of split z at + z * slab
     long long slab;
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
-    const uint16_t* zero;     // >= 16 bytes of zeros
     int xcd;                  // 1: XCD-aware tile order
 };
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st);
-static const int NCFG_BF16 = 4;
-static const int kCfgBf16[NCFG_BF16][4] = {{128, 128, 2, 2}, {256, 128, 4, 2}, {128, 256, 2, 4}, {256, 256, 2, 4}};
+static const int NCFG_BF16 = 11;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
+static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1}, {320, 256, 1},
+                                           {192, 256, 1}, {256, 128, 1}, {256, 256, 1}, {256, 128, 1}, {192, 256, 1}};
 
 }  // namespace mcrn

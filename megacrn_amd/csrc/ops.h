@@ -788,32 +788,59 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {        // finite values
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-// dst[i] = bf16(src[i]) and optionally cen[i] = bf16(src[i] - colsum[i % ld] * inv_rows), 8 elements per thread
-// (ld % 8 == 0).  `cen` is the plane centred over its rows (nodes): the adjacency gradient dP x X^T only enters the
-// row-softmax backward, which is blind to anything constant along a row of dS, so the node-mean of X can be removed
-// BEFORE rounding to bf16 - that mean is what makes the softmax backward cancel catastrophically on large graphs.
-__global__ void k_plane_to_bf16(const float* __restrict__ src, long long n8, int ld, uint4* __restrict__ dst,
-                                uint4* __restrict__ cen, const float* __restrict__ colsum, float inv_rows) {
+// fp32 planes [np][N][ld] (plane stride ps_src) -> bf16 planes [np][Kp][ldp] with ZERO pad rows / columns (the operand
+// contract of gemm_bf16.h), optionally also the plane centred over its rows (nodes):
+//   dst = bf16(src) ; cen = bf16(src - colsum[col] * inv_rows).
+// `cen` exists because the adjacency gradient dP x X^T only enters the row-softmax backward, which is blind to anything
+// constant along a row of dS: the node-mean of X can be removed BEFORE rounding to bf16, and that mean is exactly what
+// makes the softmax backward cancel catastrophically on large, nearly uniform supports.  8 elements per thread.
+__global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src, int N, int ld, int nvalid, int Kp, int ldp,
+                                int np, uint4* __restrict__ dst, uint4* __restrict__ cen, const float* __restrict__ colsum,
+                                float inv_rows) {
+    const int c8n = ldp / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    if (dst) {
-        unsigned w[4];
+    const long long per_plane = (long long)Kp * c8n;
+    if (i >= per_plane * np) return;
+    const int pl = (int)(i / per_plane);
+    const long long q = i - (long long)pl * per_plane;
+    const int row = (int)(q / c8n), c0 = (int)(q - (long long)row * c8n) * 8;
+    unsigned w[4] = {0u, 0u, 0u, 0u}, wc[4] = {0u, 0u, 0u, 0u};
+    if (row < N && c0 < ld) {                                    // ld % 8 == 0: a chunk is all-in or all-out
+        const float* s = src + (long long)pl * ps_src + (long long)row * ld + c0;
+        const float4 a = reinterpret_cast<const float4*>(s)[0], b = reinterpret_cast<const float4*>(s)[1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (c0 + 8 > nvalid)                                     // columns nvalid .. ld-1 of the source are not data
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c0 + j < nvalid ? v[j] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = bf16_rne(v[2 * j]) | (bf16_rne(v[2 * j + 1]) << 16);
-        dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    if (cen) {
-        const int c0 = (int)((8 * i) % ld);
-        unsigned w[4];
+        if (cen) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float m0 = colsum[c0 + 2 * j] * inv_rows, m1 = colsum[c0 + 2 * j + 1] * inv_rows;
-            w[j] = bf16_rne(v[2 * j] - m0) | (bf16_rne(v[2 * j + 1] - m1) << 16);
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = colsum[c0 + 2 * j] * inv_rows, m1 = colsum[c0 + 2 * j + 1] * inv_rows;
+                wc[j] = bf16_rne(v[2 * j] - m0) | (bf16_rne(v[2 * j + 1] - m1) << 16);
+            }
         }
-        cen[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    if (dst) dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (cen) cen[i] = make_uint4(wc[0], wc[1], wc[2], wc[3]);
+}
+
+// colsum[c] = (N / nsamp) * sum over nsamp evenly spaced rows of X[row][c]: an ESTIMATE of the column sums over all N
+// rows.  The centring above is exact for ANY vector subtracted from every row (it only has to be the same vector for
+// all rows); what matters numerically is that the bulk of the common component is gone, so a 64-row sample replaces
+// a full pass over the plane.
+__global__ __launch_bounds__(256) void k_colsum_sample(const float* __restrict__ X, long long ld, int N, int C, int nsamp,
+                                                       float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;       // 64 columns x 4 row lanes: independent loads in flight
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int i = rl; i < nsamp; i += 4) s += X[(long long)(((long long)i * N) / nsamp) * ld + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[c] = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) * ((float)N / (float)nsamp);
 }
 
 // One block of the stacked adjacency operand of the propagation GEMM (model/MegaCRN.py:20-25 as ONE product):

@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
     const int seglen = argc > 3 ? atoi(argv[3]) : 1843, nseg = argc > 4 ? atoi(argv[4]) : 1;
     const bool btr = argc > 5 ? !strcmp(argv[5], "nn") : true;
     const int cfg = argc > 6 ? atoi(argv[6]) : 0, nsplit = argc > 7 ? atoi(argv[7]) : 1, reps = argc > 8 ? atoi(argv[8]) : 20;
+    const int with_cb = argc > 9 ? atoi(argv[9]) : 0;
     const int Kp = (seglen + 63) / 64 * 64;            // padded segment (A rows are zero beyond seglen)
     const long long lda = (long long)nseg * Kp;
     std::mt19937 rng(1234);
@@ -55,14 +56,19 @@ int main(int argc, char** argv) {
         for (int s = 0; s < nseg; ++s)
             for (int k = 0; k < seglen; ++k) hA[(size_t)m * lda + (size_t)s * Kp + k] = f2bf(U(rng));
     long long ldb, bseg;
-    if (btr) {   // B[seg][k][n], n contiguous, N columns (ld = N), garbage-free only for k < seglen
-        ldb = N; bseg = (long long)seglen * N;
-        hB.resize((size_t)nseg * seglen * N);
-    } else {     // B[n][seg][k]: rows of nseg*seglen... use [n][lda-like] with its own padding-free stride
-        ldb = (long long)nseg * seglen; bseg = seglen;
-        hB.resize((size_t)N * ldb);
+    if (btr) {   // B[seg][k][n], n contiguous, k rows padded to Kp with zeros
+        ldb = N; bseg = (long long)Kp * N;
+        hB.assign((size_t)nseg * Kp * N, 0);
+        for (int s = 0; s < nseg; ++s)
+            for (int k = 0; k < seglen; ++k)
+                for (int n = 0; n < N; ++n) hB[(size_t)s * bseg + (size_t)k * ldb + n] = f2bf(U(rng));
+    } else {     // B[n][seg][k], k padded to Kp with zeros (same layout as A)
+        ldb = lda; bseg = Kp;
+        hB.assign((size_t)N * ldb, 0);
+        for (int n = 0; n < N; ++n)
+            for (int s = 0; s < nseg; ++s)
+                for (int k = 0; k < seglen; ++k) hB[(size_t)n * ldb + (size_t)s * Kp + k] = f2bf(U(rng));
     }
-    for (auto& v : hB) v = f2bf(U(rng));
     uint16_t *dA, *dB, *dZ; float *dC; uint16_t* dCb;
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2 + 256)); CK(hipMalloc(&dZ, 256));
     const int ns = nsplit < 1 ? 1 : nsplit;
@@ -74,8 +80,7 @@ int main(int argc, char** argv) {
     p.A = dA; p.B = dB; p.am = rm_plain(lda); p.bm = rm_plain(ldb); p.ldb = ldb;
     p.nseg = nseg; p.seg_len = seglen; p.a_seg = Kp; p.b_seg = bseg; p.M = M; p.N = N;
     p.C = dC; p.cm = rm_plain(N); p.alpha = 1.f; p.beta = 0.f; p.slab = (long long)M * N;
-    p.Cb = ns == 1 ? dCb : nullptr; p.cbm = rm_plain(N); p.zero = dZ; p.xcd = 1;
-    if (!btr && (seglen & 7)) { printf("nt needs seglen %% 8 == 0\n"); return 2; }
+    p.Cb = (ns == 1 && with_cb) ? dCb : nullptr; p.cbm = rm_plain(N); p.xcd = 1;
     hipError_t e = launch_gemm_bf16(p, btr, cfg, nsplit, 0);
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 2; }
     CK(hipDeviceSynchronize());
@@ -100,7 +105,7 @@ int main(int argc, char** argv) {
             double got = 0;
             for (int z = 0; z < ns; ++z) got += hC[(size_t)z * M * N + (size_t)m * N + n];
             maxerr = fmax(maxerr, fabs(got - s)); maxref = fmax(maxref, fabs(s));
-            if (ns == 1) maxerr_b = fmax(maxerr_b, fabs(bf2f(hCb[(size_t)m * N + n]) - s));
+            if (ns == 1 && with_cb) maxerr_b = fmax(maxerr_b, fabs(bf2f(hCb[(size_t)m * N + n]) - s));
         }
     }
     printf("M=%d N=%d K=%dx%d %s cfg=%d split=%d : max|err|=%.3e (max|ref|=%.3e, rel %.2e) bf16copy err %.3e rows %d\n", M, N, nseg, seglen,
