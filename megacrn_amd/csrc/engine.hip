@@ -314,7 +314,7 @@ static std::map<Bf16Key, int> g_tuned_bf16;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
-    static const double eff[NCFG_BF16] = {0.6, 0.8, 1.0, 0.9, 0.9, 0.9, 0.85, 0.7};
+    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8};
     int best = 0; double bt = 1e300;
     for (int c = 0; c < NCFG_BF16; ++c) {
         const int per_cu = kCfgBf16[c][2];
@@ -488,7 +488,8 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
-                         float* dT = nullptr, bool* used_dT = nullptr, uint16_t* dPb = nullptr) {
+                         float* dT = nullptr, bool* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
+                         bool cell_ds_last = true) {
     if (used_dT) *used_dT = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
@@ -550,29 +551,41 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     if (u.defer) {
         // nothing here: d1t / e2 stay in this call's plane set and are consumed by the deferred launch
     } else if (small && aligned16(X) && ds_small_enabled()) {   // output-stationary adjacency-gradient kernel (prop_small.h)
-        DsP q;
-        memset(&q, 0, sizeof q);
-        q.nseg = s.K == 3 ? 2 : 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.ldc = u.ldS; q.slab = u.slab;
+        // The two AGCN calls of a cell (update first, gate second) share ONE launch: every workgroup adds both calls'
+        // products to its slab partial while it sits in the accumulators, so the slab is read and written once per cell
+        // instead of once per call (the slab read-modify-write was ~1/3 of this kernel's HBM bytes, profiles/r1).
+        DsP q_local;
+        DsP& q = cell_ds ? *cell_ds : q_local;
+        if (!cell_ds || cell_ds->nseg == 0) memset(&q, 0, sizeof q);
+        const int s0 = q.nseg, own = s.K == 3 ? 2 : 1;
+        q.nseg = s0 + own; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.ldc = u.ldS; q.slab = u.slab;
         for (int b = 0; b < 2; ++b) {
             const long long g1 = 1 + b * (s.K - 1);
-            q.A[b][0] = dP + g1 * s.PS;       q.B[b][0] = X;                      // d1t x0^T
-            q.A[b][1] = dP + (g1 + 1) * s.PS; q.B[b][1] = X + g1 * s.PS;          // e2  x1^T
+            q.A[b][s0] = dP + g1 * s.PS;       q.B[b][s0] = X;                      // d1t x0^T
+            if (own == 2) { q.A[b][s0 + 1] = dP + (g1 + 1) * s.PS; q.B[b][s0 + 1] = X + g1 * s.PS; }   // e2  x1^T
             q.C[b] = u.dS + (long long)b * u.sup_stride;
         }
-        const double ex = 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
-        hipStream_t ds_st = st;
-        if (side) {
-            CK(hipEventRecord(g_side.ready[buf], st));
-            CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
-            ds_st = g_side.st;
-        }
-        {
-            hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
-            MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st), ex, 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
-        }
-        if (side) {
-            CK(hipEventRecord(g_side.done[buf], g_side.st));
-            g_side.pending[buf] = true; g_side.any = true;
+        if (!cell_ds || cell_ds_last) {
+            const double ex = 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
+            hipStream_t ds_st = st;
+            if (side) {
+                CK(hipEventRecord(g_side.ready[buf], st));
+                CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
+                ds_st = g_side.st;
+            }
+            {
+                hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
+                MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st), ex, 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
+            }
+            if (side) {
+                const int nb_ = cell_ds ? 2 : 1;          // a merged launch reads the plane sets of both calls
+                for (int i = 0; i < nb_; ++i) {
+                    const int bi = cell_ds ? i : buf;
+                    CK(hipEventRecord(g_side.done[bi], g_side.st));
+                    g_side.pending[bi] = true;
+                }
+                g_side.any = true;
+            }
         }
     } else
     {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
@@ -703,9 +716,13 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     const long long RH = s.R * s.H;
     bool xu = false, xg = false;
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr));
+    DsP cell_ds;
+    cell_ds.nseg = 0;
+    static const bool merge_ds = !(getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0);
+    DsP* cds = merge_ds ? &cell_ds : nullptr;
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg, dPb));
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg, dPb, cds, true));
     if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;

@@ -397,113 +397,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Kernel 3: FOUR waves, one per SIMD, wave tile (BM/2) x (BN/2) - up to 128 x 128 = 16 accumulator fragments in the
-// 512-register file of a lone wave.  Register blocking is what lowers the LDS traffic per MFMA (8 fragment reads feed 16
-// MFMAs; the 8-wave kernels above read 6 for 8) - with 256 x 256 tiles the LDS, not the matrix pipe, bounds those.
-// There is no partner wave to hide behind, so the wave pipelines itself:
-//   * fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of k-step s issue;
-//   * ONE barrier per 64-deep K tile, placed after the MFMAs of k-step 2: by then every wave has read the whole tile
-//     (k-step 3 is already in registers), so the barrier both publishes tile t+1 (its DMA was waited for just before)
-//     and releases tile t's stage; the DMA of tile t+2 and the first fragments of tile t+1 follow during k-step 3;
-//   * the 16 LDS-DMA instructions of a tile are interleaved with k-step 3's MFMAs in groups of four.
-// ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool BTR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(const Bf16GemmP p) {
-    constexpr int BK = 64, NT = 256, NSTAGE = 2;
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
-    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
-    static_assert(T::ASLOTS % NT == 0 && T::BSLOTS % NT == 0, "tile / workgroup mismatch");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tile_m, tile_n;
-    bf16_tile_of(p, BM, BN, tile_m, tile_n);
-    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int split = blockIdx.z;
-    const int nkt = p.nseg * p.tps;
-    const int kt_beg = split * p.tiles_per_split;
-    const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
-    if (kt_beg >= kt_end) return;
-    const int nt = kt_end - kt_beg;
-
-    T tl;
-    tl.init(p, tid, m_blk, n_blk, kt_beg);
-    int aoff[FM], boff[FN];
-    bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
-
-    f32x16_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    bf16x8_t fa[2][FM], fb[2][FN];
-#define MCRN_W4_READ(BUF, STG, KS_)                                                                     \
-    do {                                                                                                \
-        const unsigned char* sA_ = smem_bf16 + (STG) * T::STAGE;                                        \
-        const unsigned char* sB_ = sA_ + T::ASLOTS * 16;                                                \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                 \
-            fa[BUF][i] = *reinterpret_cast<const bf16x8_t*>(sA_ + (aoff[i] ^ ((KS_) << 5)));            \
-        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[BUF][j] = bf16_read_b<BN, BTR>(sB_, boff[j], KS_); \
-    } while (0)
-#define MCRN_W4_MMA(BUF)                                                                                \
-    do {                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                             \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[BUF][i], fb[BUF][j], acc[i][j], 0, 0, 0); \
-    } while (0)
-
-    tl.issue(lds_base, 0, wave);
-    if (nt > 1) tl.issue(lds_base, 1, wave);
-    if (nt > 1) MCRN_VMCNT(T::NLD_MIN); else MCRN_VMCNT(0);     // tile 0 landed (tile 1 may still fly)
-    __syncthreads();
-    MCRN_W4_READ(0, 0, 0);
-    for (int t = 0; t < nt; ++t) {
-        const int stg = t & 1;
-        MCRN_W4_READ(1, stg, 1);
-        MCRN_W4_MMA(0);
-        MCRN_W4_READ(0, stg, 2);
-        MCRN_W4_MMA(1);
-        MCRN_W4_READ(1, stg, 3);
-        MCRN_W4_MMA(0);
-        // every fragment of tile t is in registers; tile t+1 (this wave's share) has landed once nothing is in flight
-        MCRN_VMCNT(0);
-        __syncthreads();                                         // tile t+1 visible to all, stage of tile t free
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nt) MCRN_W4_READ(0, stg ^ 1, 0);
-        if (t + 2 < nt) {                                        // DMA of tile t+2 into tile t's stage, between the MFMAs
-            const uint16_t* __restrict__ Ab = tl.baseA + (long long)tl.iss_seg * tl.stepA_seg + tl.iss_lt * BK;
-            const uint16_t* __restrict__ Bb = tl.baseB + (long long)tl.iss_seg * tl.stepB_seg + (long long)(tl.iss_lt * BK) * tl.stepB_k;
-            const unsigned sA = lds_base + stg * T::STAGE + wave * 1024;
-            const unsigned sB = sA + T::ASLOTS * 16;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = i * T::AJ / FM; j < (i + 1) * T::AJ / FM; ++j) glds16(Ab, tl.offA[j], sA + j * NT * 16);
-#pragma unroll
-                for (int j = i * T::BJ / FM; j < (i + 1) * T::BJ / FM; ++j) glds16(Bb, tl.offB[j], sB + j * NT * 16);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (++tl.iss_lt == tl.tps) { tl.iss_lt = 0; ++tl.iss_seg; }
-        } else {
-            MCRN_W4_MMA(1);
-        }
-    }
-#undef MCRN_W4_READ
-#undef MCRN_W4_MMA
-    bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
-}
-
 // ---- host side ----------------------------------------------------------------------------------
 static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
     p.tps = (p.seg_len + BK - 1) / BK;
@@ -547,22 +440,6 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
-template <int BM, int BN, bool BTR>
-static inline hipError_t launch_one_bf16_w4(Bf16GemmP p, int nsplit, hipStream_t st) {
-    bf16_split_plan(p, 64, nsplit);
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<BM, BN, BTR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_w4_kernel<BM, BN, BTR>), dim3(tiles, 1, p.nsplit), dim3(256), lds, st, p);
-    return hipGetLastError();
-}
 template <bool BTR>
 static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
@@ -574,9 +451,8 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
         case 5: return launch_one_bf16_pp<320, 256, 32, 4, BTR>(p, nsplit, st);      // 144 KB   1   ping-pong
         case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR>(p, nsplit, st);      // 112 KB   1   ping-pong
         case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR>(p, nsplit, st);      //  96 KB   1   ping-pong
-        case 8: return launch_one_bf16_w4<256, 256, BTR>(p, nsplit, st);             // 128 KB   1   4 waves, 128 x 128 each
-        case 9: return launch_one_bf16_w4<256, 128, BTR>(p, nsplit, st);             //  96 KB   1   4 waves, 128 x 64 each
-        default: return launch_one_bf16_w4<192, 256, BTR>(p, nsplit, st);            // 112 KB   1   4 waves, 96 x 128 each
+        case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
+        default: return launch_one_bf16_pp<256, 128, 64, 2, BTR>(p, nsplit, st);     //  96 KB   1   ping-pong, 64-deep phases
     }
 }
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st) {

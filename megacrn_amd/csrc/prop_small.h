@@ -549,8 +549,8 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
 // fragment feeds NF x 3 MFMAs (21 at N = 207) instead of 3 in the tiled GEMM: MFMA-bound by design.
 // ---------------------------------------------------------------------------------------------
 struct DsP {
-    const float* A[2][2];       // [support][segment]
-    const float* B[2][2];
+    const float* A[2][4];       // [support][segment]  (2 segments per AGCN call at cheb_k = 3; a cell's two calls share one launch)
+    const float* B[2][4];
     float* C[2];                // slab 0 of the support; slab z at + z*slab
     long long slab;
     int nseg, N, ncols, kchunk; // kchunk multiple of 16
@@ -609,8 +609,12 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
                 const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
                 const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
                 const int base = (((op * NF + fj) * 2 + ks) * 2) * 64;          // uint4 index of [op][fj][ks][hi][0]
-                g[(base + slot) * 2 + half] = make_uint2(h01, h23);
-                g[(base + 64 + slot) * 2 + half] = make_uint2(l01, l23);
+                // slot permutation inside the 64-slot array: the 8-byte stores of the four (ks, k-half) lanes of one
+                // row would otherwise fall on the same banks (sub-array strides are multiples of 128 bytes): 4-way
+                // conflicts, 1.07 M conflict cycles per launch (profiles/r1).  The readers apply the same XOR.
+                const int ps = slot ^ (kq8 << 1) ^ (ks << 2);
+                g[(base + ps) * 2 + half] = make_uint2(h01, h23);
+                g[(base + 64 + ps) * 2 + half] = make_uint2(l01, l23);
             }
         }
     };
@@ -650,12 +654,13 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
         MCRN_TLA(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[stg][0][w][ks][0][lane]);
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[stg][0][w][ks][1][lane]);
+            const int pl = lane ^ (kq << 1) ^ (ks << 2);              // see publish()
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[stg][0][w][ks][0][pl]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[stg][0][w][ks][1][pl]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, img[stg][1][j][ks][0][lane]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, img[stg][1][j][ks][1][lane]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, img[stg][1][j][ks][0][pl]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, img[stg][1][j][ks][1][pl]);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
@@ -780,8 +785,9 @@ __global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
                 const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
                 const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
                 const int base = (((op * NF + fj) * 2 + ks) * 2) * 64;
-                g[(base + slot) * 2 + half] = make_uint2(h01, h23);
-                g[(base + 64 + slot) * 2 + half] = make_uint2(l01, l23);
+                const int ps = slot ^ (kq8 << 1) ^ (ks << 2);                    // bank-conflict-free slot order (see ds_small_kernel)
+                g[(base + ps) * 2 + half] = make_uint2(h01, h23);
+                g[(base + 64 + ps) * 2 + half] = make_uint2(l01, l23);
             }
         }
     };
@@ -792,18 +798,19 @@ __global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][lane]);
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[0][w][ks][1][lane]);
+            const int pl = lane ^ (kq << 1) ^ (ks << 2);
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][pl]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[0][w][ks][1][pl]);
             // product-outer order: the NF accumulators are independent chains
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, __builtin_bit_cast(bf16x8, img[1][j][ks][0][lane]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, __builtin_bit_cast(bf16x8, img[1][j][ks][0][pl]), acc[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][1][lane]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][1][pl]), acc[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][0][lane]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][0][pl]), acc[j], 0, 0, 0);
         }
         __syncthreads();
     }

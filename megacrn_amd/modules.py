@@ -211,6 +211,33 @@ class _MemoryFn(torch.autograd.Function):
         return dh, dMem, dWq
 
 
+class _ProjFn(torch.autograd.Function):
+    """``proj`` = nn.Linear(H_dec, output_dim) of the multi-layer path (model/MegaCRN.py:144,186) on the library's own
+    MFMA GEMM (``mcrn_gemm_f32``) - no vendor BLAS on any product path.  y = x W^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _need_gpu(x, "proj")
+        x, W, b = _f32c(x), _f32c(W), _f32c(b)
+        R, K, O = x.numel() // x.shape[-1], x.shape[-1], W.shape[0]
+        y = b.expand(R, O).contiguous()
+        check(lib.mcrn_gemm_f32(R, O, K, 0, 1, _p(x), _p(W), _p(y), 1.0, 1.0, 1, None, _stream()), "proj gemm")
+        ctx.save_for_backward(x, W)
+        return y.view(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, K, O = x.numel() // x.shape[-1], x.shape[-1], W.shape[0]
+        dx, dW = torch.empty_like(x), torch.empty_like(W)
+        st = _stream()
+        check(lib.mcrn_gemm_f32(R, K, O, 0, 0, _p(dy), _p(W), _p(dx), 1.0, 0.0, 1, None, st), "proj dx")       # dy W
+        slabs = torch.empty(64 * O * K, device=x.device)
+        check(lib.mcrn_gemm_f32(O, K, R, 1, 0, _p(dy), _p(x), _p(dW), 1.0, 0.0, 64, _p(slabs), st), "proj dW")  # dy^T x
+        return dx, dW, dy.reshape(R, O).sum(0)
+
+
 class _ModelFn(torch.autograd.Function):
     """Whole MegaCRN.forward (model/MegaCRN.py:168-194) as one autograd node (num_layers == 1)."""
 
@@ -446,8 +473,8 @@ class MegaCRN(nn.Module):
         return self._forward_composed(x, y_cov, labels, batches_seen)
 
     def _forward_composed(self, x, y_cov, labels=None, batches_seen=None):
-        """num_layers > 1: same data flow as the reference forward (:168-194), every op a HIP node
-        (supports, cells, memory head); torch only concatenates, stacks and applies ``proj``."""
+        """num_layers > 1: same data flow as the reference forward (:168-194), every arithmetic op a HIP node of this
+        library (supports, cells, memory head, projection); torch only concatenates and stacks tensors."""
         B = x.shape[0]
         supports = list(_SupportsFn.apply(self.memory['We1'], self.memory['We2'], self.memory['Memory']))
         zeros = [s.to(x.device) for s in self.encoder.init_hidden(B)]
@@ -460,7 +487,7 @@ class MegaCRN(nn.Module):
         preds = []
         for t in range(self.horizon):
             top, dec_state = self.decoder(torch.cat([go, y_cov[:, t]], dim=-1), dec_state, supports)
-            go = self.proj(top)
+            go = _ProjFn.apply(top, self.proj[0].weight, self.proj[0].bias)
             preds.append(go)
             if teacher[t]:
                 go = labels[:, t]
