@@ -30,7 +30,8 @@ CONFIGS = {
     "syn8192": dict(N=8192, B=32, T=12, H=64, M=20, D=64, label="synthetic N=8192"),
 }
 SC_MEAN, SC_STD = 54.4, 19.5
-PEAK = {"f32": 157.3e12, "bf16x3": 2500e12, "bf16": 2500e12}   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
+PEAK = {"f32": 157.3e12, "bf16x3": 2500e12, "bf16": 2500e12}
+HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: HBM3E 8 TB/s   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
 ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
 
 
@@ -66,17 +67,41 @@ def pmc_traffic(config_name, dtype, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 per
     MI355X_MICROARCH.md).  None when no profile of this config is committed."""
-    path = os.path.join(ROOT, "profiles", "r1", f"traffic_{config_name}.json")
-    if not os.path.exists(path):
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, f"traffic_{config_name}.json")
+        if os.path.exists(path):
+            break
+    else:
         return None
     d = json.load(open(path))
-    key = "prop2_fwd_kernel" if (N <= 256 and dtype == "bf16x3") else "true, false, 1>"
+    if dtype == "bf16":
+        keys = ("true, 1>",)                      # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
+    elif N <= 256 and dtype == "bf16x3":
+        keys = ("prop2_fwd_kernel",)
+    else:
+        keys = ("true, false, 1>",)               # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
     tot = n = 0
     for k, v in d.items():
-        if key in k:
+        if any(key in k for key in keys) and ("gemm_bf16_" in k or dtype != "bf16"):
             tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
+
+
+def propagation_alg_bytes(cfg, B, dtype):
+    """Algorithmic HBM bytes of ONE forward propagation launch, averaged over the encoder and decoder launches of a
+    step like the flops (read the supports once, the input plane once, write the propagated planes)."""
+    N, H, D, K = cfg["N"], cfg["H"], cfg["D"], 3
+    out = []
+    for C in (1 + H, 2 + H + D):
+        if dtype == "bf16":       # stacked bf16 adjacency (2(K-1) blocks), bf16 input plane, fp32 output planes
+            out.append(2 * (K - 1) * N * N * 2 + N * B * C * 2 + 2 * (K - 1) * N * B * C * 4)
+        else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
+            out.append(2 * N * N * 4 + N * B * C * 4 + 2 * (K - 1) * N * B * C * 4)
+    per_call = sum(out) / 2.0
+    # bf16x3 at N > 256 launches one hop at a time (2 launches per AGCN call): half the bytes per launch
+    hops_per_launch = 1 if (dtype != "bf16" and N > 256) else 2
+    return per_call * hops_per_launch / 2.0
 
 
 def cpu_model_string():
@@ -217,17 +242,32 @@ def main():
         ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
         torch.cuda.synchronize()
         check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
-        ach = af.value / (ms.value * 1e-3)
         kname = ("mcrn::gemm_bf16_kernel<BM,BN,..,BTR=true> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
                  "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 256 and dtype == "bf16x3" else
                  "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
-        roof = {"bound": "mfma", "kernel": kname + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
-                "achieved": round(ach / 1e12, 3), "peak": round(PEAK[dtype] / 1e12, 1), "unit": "TFLOP/s",
-                "frac": round(ach / PEAK[dtype], 5), "traffic": pmc_traffic(args.config, dtype, cfg["N"]),
-                "note": "achieved = algorithmic fp32 flops (2 N^2 B C per support and hop) / HIP-event kernel time; traffic = corrected PMC HBM bytes per launch (profiles/r1)"
-                        + ("; bf16x3 issues 3 bf16 MFMAs per product, ceiling 833 TF" if dtype == "bf16x3" else ""),
+        launch_s = ms.value * 1e-3 / n.value
+        alg_flops = af.value / n.value
+        alg_bytes = propagation_alg_bytes(cfg, B, dtype)
+        ai = alg_flops / alg_bytes
+        ridge = PEAK[dtype] / HBM_PEAK
+        frac_mfma, frac_hbm = alg_flops / launch_s / PEAK[dtype], alg_bytes / launch_s / HBM_PEAK
+        bound = "mfma" if ai >= ridge else "hbm"
+        roof = {"bound": bound, "kernel": kname + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
+                "achieved": round(alg_flops / launch_s / 1e12, 3) if bound == "mfma" else round(alg_bytes / launch_s / 1e9, 1),
+                "peak": round(PEAK[dtype] / 1e12, 1) if bound == "mfma" else HBM_PEAK / 1e9,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 5),
+                "traffic": pmc_traffic(args.config, dtype, cfg["N"]),
+                "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
+                "frac_of_mfma_peak": round(frac_mfma, 5), "frac_of_hbm_peak": round(frac_hbm, 5),
+                "achieved_tflops": round(alg_flops / launch_s / 1e12, 3), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 1),
+                "note": "bound chosen by algorithmic intensity (flops / algorithmic bytes) vs the ridge peak_flops / 8 TB/s; "
+                        "achieved = algorithmic flops (2 N^2 B C per support and hop, true channel count) or algorithmic bytes "
+                        "(supports + input plane + propagated planes, once each) / HIP-event launch time; traffic = corrected "
+                        "PMC HBM bytes per launch (profiles/r2, tools/pmc_traffic.sh)"
+                        + ("; bf16x3 issues 3 bf16 MFMAs per product: its matrix-core ceiling is 833 TF" if dtype == "bf16x3" else ""),
                 "avg_launch_us": round(1e3 * ms.value / n.value, 3), "launches": n.value,
-                "alg_flops_per_launch": af.value / n.value}
+                "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes}
         sync_all()
 
     cpu = None

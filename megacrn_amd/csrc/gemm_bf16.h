@@ -178,33 +178,71 @@ __device__ __forceinline__ bf16x8_t bf16_read_b(const unsigned char* sB, int bof
     return *reinterpret_cast<const bf16x8_t*>(sB + (boff ^ (ks << 5)));
 }
 
-// epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+// epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
+// Output rows are plain-strided in every use of this library (stacked planes / stacked N x N blocks are contiguous:
+// the host folds such two-level maps into a plain stride), so a fragment is addressed as a SCALAR 64-bit base (its
+// first row) + a 32-bit lane offset, and fragments that lie completely inside the matrix - wave-uniform test - store
+// unpredicated.  (The first version evaluated a two-level row map with an integer division per element and a bounds
+// branch per store: ~6000 instructions, 15-25 % of a K = 1843 launch.)
 template <int FM, int FN>
 __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int split, int r_base, int c_base,
                                               int lane) {
     const int l31 = lane & 31, kq = lane >> 5;
     float* __restrict__ C = p.C ? p.C + (long long)split * p.slab : nullptr;
     const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + (long long)split * p.slab : nullptr;
+    const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
+    const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
+    const bool cols_in = cw + 32 * FN <= p.N;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int r0 = r_base + i * 32 + 4 * kq;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = r0 + (v & 3) + 8 * (v >> 2);
-            if (r >= p.M) continue;
-            const long long ro = rm_off(p.cm, r);
-            const long long rob = p.Cb ? rm_off(p.cbm, r) : 0;
+        const int rb = rw + 32 * i;                                  // first row of the fragment (scalar)
+        if (rb >= p.M) break;
+        const long long base = (long long)rb * ld + cw;
+        const unsigned lo0 = (unsigned)(4 * kq * ld + l31);
+        float* __restrict__ Cf = C ? C + base : nullptr;
+        const float* __restrict__ Cif = Cin ? Cin + base : nullptr;
+        uint16_t* __restrict__ Cbf = p.Cb ? p.Cb + (long long)rb * ldb + cw : nullptr;
+        const unsigned lb0 = (unsigned)(4 * kq * ldb + l31);
+        if (cols_in && rb + 32 <= p.M) {                             // whole fragment inside: straight-line code
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int c = c_base + j * 32 + l31;
-                if (c >= p.N) continue;
-                float o = p.alpha * acc[i][j][v];
-                if (Cin) o += p.beta * Cin[ro + c];
-                if (C) C[ro + c] = o;
-                if (p.Cb) {
-                    unsigned u = __float_as_uint(o);
-                    u += 0x7FFFu + ((u >> 16) & 1u);             // round to nearest even (finite values)
-                    p.Cb[rob + c] = (uint16_t)(u >> 16);
+                float x[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) x[v] = p.alpha * acc[i][j][v];
+                if (Cif) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) x[v] += p.beta * Cif[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + 32 * j];
+                }
+                if (Cf) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) Cf[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + 32 * j] = x[v];
+                }
+                if (Cbf) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        unsigned u = __float_as_uint(x[v]);
+                        u += 0x7FFFu + ((u >> 16) & 1u);             // round to nearest even (finite values)
+                        Cbf[lb0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ldb) + 32 * j] = (uint16_t)(u >> 16);
+                    }
+                }
+            }
+        } else {                                                     // edge fragment: per-element predicate
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dr = (v & 3) + 8 * (v >> 2);
+                    if (rb + 4 * kq + dr < p.M && cw + 32 * j + l31 < p.N) {
+                        const unsigned o = lo0 + (unsigned)(dr * ld) + 32 * j;
+                        float x = p.alpha * acc[i][j][v];
+                        if (Cif) x += p.beta * Cif[o];
+                        if (Cf) Cf[o] = x;
+                        if (Cbf) {
+                            unsigned u = __float_as_uint(x);
+                            u += 0x7FFFu + ((u >> 16) & 1u);
+                            Cbf[lb0 + (unsigned)(dr * ldb) + 32 * j] = (uint16_t)(u >> 16);
+                        }
+                    }
                 }
             }
         }
@@ -217,7 +255,9 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
 //     multiply tile t, fragment reads and MFMAs interleaved by the compiler ; issue the DMA of tile t+NSTAGE-1 into the
 //     stage tile t-1 just left (after the MFMAs in program order: they run while the addresses are formed).
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR>
+// (ROLE only changes the symbol name, so that rocprofv3 reports the forward propagation, its transpose and the
+//  adjacency gradient separately: 1 / 4 / 5 as in gemm_f32.h, 0 = everything else)
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16GemmP p) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
@@ -295,7 +335,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
 //     phase 2t+1 : G0 compute(t) | G1 load(t)           released by the barrier that ended phase 2t-1)
 // and waits (counted vmcnt) for its share of tile t+1 before the barrier that ends phase 2t+1.
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     constexpr int WGM = 2, WGN = 4, NT = 512;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
@@ -406,7 +446,7 @@ static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
     p.tiles_per_split = (nkt + nsplit - 1) / nsplit;
     p.nsplit = (nkt + p.tiles_per_split - 1) / p.tiles_per_split;
 }
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE>
 static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st) {
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -414,16 +454,16 @@ static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR>), dim3(tiles, 1, p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles, 1, p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
     return hipGetLastError();
 }
-template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
 static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t st) {
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -431,34 +471,42 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
-template <bool BTR>
+template <bool BTR, int ROLE>
 static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
-        case 0: return launch_one_bf16<128, 128, 2, 2, 64, 2, BTR>(p, nsplit, st);   //  64 KB   2
-        case 1: return launch_one_bf16<256, 128, 4, 2, 64, 3, BTR>(p, nsplit, st);   // 144 KB   1
-        case 2: return launch_one_bf16<256, 256, 2, 4, 64, 2, BTR>(p, nsplit, st);   // 128 KB   1
-        case 3: return launch_one_bf16_pp<256, 256, 32, 4, BTR>(p, nsplit, st);      // 128 KB   1   ping-pong
-        case 4: return launch_one_bf16_pp<256, 256, 64, 2, BTR>(p, nsplit, st);      // 128 KB   1   ping-pong, 64-deep phases
-        case 5: return launch_one_bf16_pp<320, 256, 32, 4, BTR>(p, nsplit, st);      // 144 KB   1   ping-pong
-        case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR>(p, nsplit, st);      // 112 KB   1   ping-pong
-        case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR>(p, nsplit, st);      //  96 KB   1   ping-pong
-        case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
-        default: return launch_one_bf16_pp<256, 128, 64, 2, BTR>(p, nsplit, st);     //  96 KB   1   ping-pong, 64-deep phases
+        case 0: return launch_one_bf16<128, 128, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);   //  64 KB   2
+        case 1: return launch_one_bf16<256, 128, 4, 2, 64, 3, BTR, ROLE>(p, nsplit, st);   // 144 KB   1
+        case 2: return launch_one_bf16<256, 256, 2, 4, 64, 2, BTR, ROLE>(p, nsplit, st);   // 128 KB   1
+        case 3: return launch_one_bf16_pp<256, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong
+        case 4: return launch_one_bf16_pp<256, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong, 64-deep phases
+        case 5: return launch_one_bf16_pp<320, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 144 KB   1   ping-pong
+        case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong
+        case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
+        default: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);     //  96 KB   1   ping-pong, 64-deep phases
     }
 }
-hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st) {
+hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.seg_len <= 0) return hipSuccess;
+    // stacked outputs whose blocks are contiguous ((r / inner) * hi + (r % inner) * lo with hi == inner * lo) are plain rows
+    if (p.cm.inner > 0 && p.cm.hi == (long long)p.cm.inner * p.cm.lo) p.cm = rm_plain(p.cm.lo);
+    if (p.cbm.inner > 0 && p.cbm.hi == (long long)p.cbm.inner * p.cbm.lo) p.cbm = rm_plain(p.cbm.lo);
+    if (p.cm.inner > 0 || (p.Cb && p.cbm.inner > 0)) return hipErrorInvalidValue;   // the epilogue addresses plain-strided rows
     if (btr && ((p.N & 7) || p.N < 8)) return hipErrorInvalidValue;     // [k][n] operands are fetched in 8-column chunks
-    return btr ? launch_cfg_bf16<true>(p, cfg, nsplit, st) : launch_cfg_bf16<false>(p, cfg, nsplit, st);
+    // each hot role uses one storage form of B; everything else is "misc"
+    if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
+    if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);
+    if (role == 5 && !btr) return launch_cfg_bf16<false, 5>(p, cfg, nsplit, st);
+    return btr ? launch_cfg_bf16<true, 0>(p, cfg, nsplit, st) : launch_cfg_bf16<false, 0>(p, cfg, nsplit, st);
 }
 
 }  // namespace mcrn

@@ -42,7 +42,7 @@ struct Bf16GemmP {
 };
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
-hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, hipStream_t st);
+hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st);
 static const int NCFG_BF16 = 10;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
 static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
                                            {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1}};

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
     p.nseg = nseg; p.seg_len = seglen; p.a_seg = Kp; p.b_seg = bseg; p.M = M; p.N = N;
     p.C = dC; p.cm = rm_plain(N); p.alpha = 1.f; p.beta = 0.f; p.slab = (long long)M * N;
     p.Cb = (ns == 1 && with_cb) ? dCb : nullptr; p.cbm = rm_plain(N); p.xcd = 1;
-    hipError_t e = launch_gemm_bf16(p, btr, cfg, nsplit, 0);
+    hipError_t e = launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 2; }
     CK(hipDeviceSynchronize());
     std::vector<float> hC((size_t)ns * M * N); std::vector<uint16_t> hCb((size_t)M * N);
@@ -112,9 +112,9 @@ int main(int argc, char** argv) {
            btr ? "nn" : "nt", cfg, ns, maxerr, maxref, maxerr / maxref, maxerr_b, rows_checked);
     const bool ok = maxerr / maxref < 2e-5;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0);
+    for (int i = 0; i < 3; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0);
+    for (int i = 0; i < reps; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * M * N * (double)nseg * seglen;
