@@ -114,25 +114,34 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(cfg, sample_B, steps, nthr):
-    """The numpy oracle (a port of the reference CPU path) timed on this host, bounded sample, `nthr` BLAS threads."""
+def cpu_baseline(cfg, sample_B, sample_T, steps, nthr):
+    """The numpy oracle (a port of the reference CPU path) timed on this host on a bounded sample: `sample_B` samples,
+    sequences of `sample_T` (<= T) steps, `nthr` BLAS threads.  Returns samples/s scaled to the full sequence length."""
     from oracle import megacrn_oracle as O
     N, T, H = cfg["N"], cfg["T"], cfg["H"]
     P = O.init_params(N, rnn_units=H, mem_num=cfg["M"], mem_dim=cfg["D"], seed=0)
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
-    yc = rng.random((sample_B, T, N, 1)).astype(np.float32)
-    y = rng.standard_normal((sample_B, T, N, 1)).astype(np.float32)
+    x = rng.standard_normal((sample_B, sample_T, N, 1)).astype(np.float32)
+    yc = rng.random((sample_B, sample_T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((sample_B, sample_T, N, 1)).astype(np.float32)
     opt = O.Adam(P)
     from threadpoolctl import threadpool_limits
     with threadpool_limits(limits=nthr):
-        if nthr > 1:
-            O.train_step(P, opt, x, yc, y, [True, False] * (T // 2), SC_MEAN, SC_STD)   # warm-up (BLAS threads, page-in)
         t = time.perf_counter()
         for s in range(steps):
-            O.train_step(P, opt, x, yc, y, [s % 2 == 0] * T, SC_MEAN, SC_STD)
+            O.train_step(P, opt, x, yc, y, [(s + i) % 2 == 0 for i in range(sample_T)], SC_MEAN, SC_STD)
         dt = time.perf_counter() - t
-    return sample_B * steps / dt, dt
+    return sample_B * steps / dt * (sample_T / T), dt
+
+
+def cpu_sample(cfg, B, budget_flops):
+    """(samples, sequence length) of the CPU leg so that one train step stays within `budget_flops` algorithmic flops:
+    as many whole samples as fit (at most B/4), else one sample with a shortened sequence (cost is linear in T)."""
+    per_sample = 3.0 * alg_flops_forward(cfg, 1)
+    nb = int(budget_flops // per_sample)
+    if nb >= 1:
+        return min(nb, max(1, B // 4)), cfg["T"]
+    return 1, max(1, min(cfg["T"], int(budget_flops // (per_sample / cfg["T"]))))
 
 
 def self_launch(args):
@@ -272,18 +281,20 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # bounded sample (about 10-30 s of CPU work in total): B/4 samples on all useful cores, B/16 on ONE thread
-        # (the reference trainer pins one thread, model/traintest_MegaCRN.py:255-261)
+        # bounded sample (about 10-30 s of CPU work in total): a flop budget per leg - all useful cores, and ONE thread
+        # (the reference trainer pins one thread, model/traintest_MegaCRN.py:255-261); graphs too large for even one
+        # full sample within the budget run a shortened sequence and are scaled linearly to T
         nthr = min(32, os.cpu_count() or 1)      # more BLAS threads than this only slows these small matrices
-        sample_B = max(1, B // 4)
-        v, secs = cpu_baseline(cfg, sample_B, 2, nthr)
-        s1 = max(1, B // 16)
-        v1, secs1 = cpu_baseline(cfg, s1, 1, 1)
-        cpu = {"value": round(v, 3), "unit": "samples/s", "cores": nthr, "kind": "port",
-               "value_1thread": round(v1, 3), "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
-               "sample": f"oracle/megacrn_oracle.py (numpy port of the reference CPU path) full train step of the same "
-                         f"{cfg['label']} workload: {sample_B} of the {B} samples, {nthr} BLAS threads, 2 timed steps "
-                         f"after 1 warm-up ({secs:.1f} s); value_1thread: {s1} samples, 1 thread, 1 step ({secs1:.1f} s)"}
+        sB, sT = cpu_sample(cfg, B, 2.0e12)
+        v, secs = cpu_baseline(cfg, sB, sT, 1, nthr)
+        s1, t1 = cpu_sample(cfg, B, 0.25e12)
+        v1, secs1 = cpu_baseline(cfg, s1, t1, 1, 1)
+        cpu = {"value": round(v, 4), "unit": "samples/s", "cores": nthr, "kind": "port",
+               "value_1thread": round(v1, 4), "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
+               "sample": f"oracle/megacrn_oracle.py (numpy port of the reference CPU path), one full train step of the same "
+                         f"{cfg['label']} workload: {sB} of the {B} samples x {sT} of {cfg['T']} sequence steps on {nthr} BLAS "
+                         f"threads ({secs:.1f} s); value_1thread: {s1} samples x {t1} steps on 1 thread ({secs1:.1f} s); "
+                         f"both scaled linearly to the full sequence length"}
 
     if rank == 0:
         gb = B * world

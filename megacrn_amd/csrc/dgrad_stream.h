@@ -47,6 +47,8 @@ struct DgradP {
     const float* dY;        // [R][O]
     const uint4* Wfrag;     // k_wfrag_build image of Wd [(g, c')][o]
     float* dP;              // [G][R][Cp]  (plane stride PS)
+    unsigned short* dPb;    // MCRN_BF16: planes 1.. are written as bf16 here ([G-1][.][Cp] rows, plane stride PSb) and
+    long long PSb;          //   NOT to dP: they are only ever read as bf16 operands (S^T product, adjacency gradient)
     long long R, PS;
     int O, ncols, Cp;       // ncols = G*Cp
     int ncf, parts, cf_per_part;
@@ -154,13 +156,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         const int n = 32 * j + l31;                                    // C/D layout: column = lane & 31
         if (live && n < p.ncols && !(dbg & 1)) {
             const int g = n / p.Cp;
-            float* __restrict__ c = p.dP + (long long)g * p.PS + (n - g * p.Cp) + r0 * p.Cp;
             int cp = p.Cp;
             asm volatile("" : "+s"(cp));                               // row offsets stay scalar multiples, not 16 live VGPR pairs
+            if (p.dPb && g > 0) {                                      // bf16 gradient plane (same row / column indexing)
+                unsigned short* __restrict__ c = p.dPb + (long long)(g - 1) * p.PSb + (n - g * p.Cp) + r0 * p.Cp;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int dr = (v & 3) + 8 * (v >> 2);
-                if (rows_in || r0 + dr < p.R) c[dr * cp] = acc[v] + acx[v];
+                for (int v = 0; v < 16; ++v) {
+                    const int dr = (v & 3) + 8 * (v >> 2);
+                    unsigned u = __float_as_uint(acc[v] + acx[v]);
+                    u += 0x7FFFu + ((u >> 16) & 1u);                   // round to nearest even
+                    if (rows_in || r0 + dr < p.R) c[dr * cp] = (unsigned short)(u >> 16);
+                }
+            } else {
+                float* __restrict__ c = p.dP + (long long)g * p.PS + (n - g * p.Cp) + r0 * p.Cp;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dr = (v & 3) + 8 * (v >> 2);
+                    if (rows_in || r0 + dr < p.R) c[dr * cp] = acc[v] + acx[v];
+                }
             }
         }
         if (j + 1 < j1) MCRN_DG_PUBLISH(s ^ 1);                        // every wave left stage s^1 before the previous barrier

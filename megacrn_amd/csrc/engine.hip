@@ -384,7 +384,7 @@ static Bf16GemmP bgp(const Sup& u) {
 // plane (N x ld fp32) -> bf16 copy (propagation operand) and node-centred bf16 copy (adjacency-gradient operand)
 static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st);
 static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
-                          int nvalid);
+                          int nvalid, long long src_ps, long long dst_ps, long long mu_stride);
 
 // MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
 //   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
@@ -501,12 +501,17 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                          float* dT = nullptr, bool* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
                          bool cell_ds_last = true) {
     if (used_dT) *used_dT = false;
+    bool dgrad_wrote_bf16 = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
     if (imgd && g_precision == MCRN_BF16X3 && dgrad_stream_ok(O) && aligned16(dY)) {
         // d-grad, streaming form (dgrad_stream.h): imgd is the B-fragment image of Wd (built by wprep under the same test)
         DgradP q;
         q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp; q.dbg = g_debug;
+        q.dPb = nullptr; q.PSb = 0;
+        if (g_prop_bf16 && u.STstk && dPb && s.ldp == s.ld) {   // bf16 plane rows then coincide with the fp32 rows: write them here
+            q.dPb = dPb; q.PSb = s.PSb; dgrad_wrote_bf16 = true;
+        }
         const double fl = 2.0 * (double)s.R * O * (double)(s.G * s.Cp);
         MCRN_PROF_WRAP(ROLE_DGRAD, launch_dgrad_stream(q, st), fl, 2.0 * (double)s.R * O * (double)(s.G * s.C));
     } else {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
@@ -520,7 +525,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     }
     if (g_prop_bf16 && u.STstk && dPb) {
         // planes 1.. of dP as bf16 (operand of the S^T product now, of the stack's adjacency gradient later)
-        CKI(planes_to_bf16(s, dP + s.PS, u.nb, dPb, nullptr, nullptr, st, -1));
+        if (!dgrad_wrote_bf16) CKI(planes_to_bf16(s, dP + s.PS, u.nb, dPb, nullptr, nullptr, st, -1, -1, -1, 0));
         return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
@@ -682,19 +687,29 @@ static int colsum(const float* X, long long ld, long long rows, int C, float* pa
 static size_t colsum_part_floats(long long rows, int C, int chunk = COLSUM_CHUNK) { return (size_t)cdiv(rows, chunk) * C; }
 static const int MU_CHUNK = 64;       // rows per partial of the node-mean of a plane (wide grid: N / 64 x ld / 64 workgroups)
 static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
-                          int nvalid = -1) {
+                          int nvalid = -1, long long src_ps = -1, long long dst_ps = -1, long long mu_stride = 0) {
     const long long n = (long long)np * s.Kp * (s.ldp / 8);
-    LAUNCH(k_plane_to_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, X, s.PS, s.N, (int)s.ld, nvalid < 0 ? (int)s.ld : nvalid, s.Kp,
-           (int)s.ldp, np,
-           reinterpret_cast<uint4*>(xb), reinterpret_cast<uint4*>(xc), mu, 1.f / (float)s.N);
+    LAUNCH(k_plane_to_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, X, src_ps < 0 ? s.PS : src_ps, s.N, (int)s.ld,
+           nvalid < 0 ? (int)s.ld : nvalid, s.Kp, (int)s.ldp, np, reinterpret_cast<uint4*>(xb), reinterpret_cast<uint4*>(xc), mu,
+           1.f / (float)s.N, mu_stride, (dst_ps < 0 ? s.PSb : dst_ps) / 8);
     return 0;
 }
+// forward: only the plain bf16 copy (operand of the propagation); the centred copies are made in the backward pass
 static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st) {
-    if (xc) {
-        const int nsamp = s.N < 64 ? s.N : 64;
-        LAUNCH(k_colsum_sample, dim3(cdiv(s.ld, 64)), dim3(256), 0, st, X, s.ld, s.N, (int)s.ld, nsamp, u.mu);
+    (void)u; (void)xc;
+    return planes_to_bf16(s, X, 1, xb, nullptr, nullptr, st, -1);
+}
+// backward, once per cell stack: node-centred bf16 copies of plane 0 of EVERY AGCN call (operand of the stack's
+// adjacency-gradient product): the gate calls read plane 0 of Z_t, the update calls plane 0 of Y_t; slot 2t + a.
+static int centre_planes(const Shp& s, const Sup& u, const float* Zall, const float* Yall, int T, uint16_t* x0c_all, hipStream_t st) {
+    const int nsamp = s.N < 64 ? s.N : 64;
+    for (int a = 0; a < 2; ++a) {
+        const float* X = a ? Yall : Zall;
+        float* mu = u.mu + (long long)a * T * s.ld;
+        LAUNCH(k_colsum_sample, dim3(cdiv(s.ld, 64), T), dim3(256), 0, st, X, s.ld, s.N, (int)s.ld, nsamp, mu, s.ZT, s.ld);
+        CKI(planes_to_bf16(s, X, T, nullptr, x0c_all + (long long)a * s.PSb, mu, st, -1, s.ZT, 2 * s.PSb, s.ld));
     }
-    return planes_to_bf16(s, X, 1, xb, xc, u.mu, st, -1);
+    return 0;
 }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
@@ -1048,7 +1063,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         for (int i = 0; i < 2; ++i) P.T2[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;
         P.dA = b.take<float>((size_t)P.nb * N * P.ldS);
         const long long ldm = P.se.ld > P.sd.ld ? P.se.ld : P.sd.ld;
-        P.mu = b.take<float>((size_t)ldm);
+        P.mu = b.take<float>((size_t)2 * (d->T_in > d->T_out ? d->T_in : d->T_out) * ldm);
         P.mu_part = b.take<float>(colsum_part_floats(N, (int)ldm, MU_CHUNK) + 1024);
         P.x0b_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
         P.x0c_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
@@ -1320,6 +1335,14 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_W * od * Hd * sizeof(float), st));
+    if (P.bf16 && P.Kp > N) {   // pad rows of the bf16 gradient planes: d-grad writes the N data rows in place
+        for (int e_ = 0; e_ < 2; ++e_) {
+            const Shp& s_ = e_ ? sd : se;
+            const long long np_ = (long long)2 * (e_ ? To : Ti) * P.nb, per = (long long)(s_.Kp - N) * (s_.ldp / 8);
+            LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(e_ ? P.dPb_d : P.dPb_e),
+                   s_.PSb / 8, N, s_.Kp, (int)(s_.ldp / 8), np_);
+        }
+    }
     // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
     Sup ud = u; ud.defer = P.defer_ds;
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
@@ -1415,7 +1438,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     if (P.bf16) {
         // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
+        CKI(centre_planes(sd, u, P.Zdec, P.Ydec, To, P.x0c_d, st));
         CKI(ds_bf16(sd, u, P.dPb_d, P.x0c_d, 2 * To, P.dA, P.ldS, false, st));
+        CKI(centre_planes(se, u, P.Zenc, P.Yenc, Ti, P.x0c_e, st));
         CKI(ds_bf16(se, u, P.dPb_e, P.x0c_e, 2 * Ti, P.dA, P.ldS, true, st));
         CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,

@@ -796,13 +796,14 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {        // finite values
 // makes the softmax backward cancel catastrophically on large, nearly uniform supports.  8 elements per thread.
 __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src, int N, int ld, int nvalid, int Kp, int ldp,
                                 int np, uint4* __restrict__ dst, uint4* __restrict__ cen, const float* __restrict__ colsum,
-                                float inv_rows) {
+                                float inv_rows, long long colsum_stride, long long dst_ps8 /* uint4 between output planes */) {
     const int c8n = ldp / 8;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_plane = (long long)Kp * c8n;
-    if (i >= per_plane * np) return;
-    const int pl = (int)(i / per_plane);
-    const long long q = i - (long long)pl * per_plane;
+    if (i0 >= per_plane * np) return;
+    const int pl = (int)(i0 / per_plane);
+    const long long q = i0 - (long long)pl * per_plane;
+    const long long i = (long long)pl * dst_ps8 + q;
     const int row = (int)(q / c8n), c0 = (int)(q - (long long)row * c8n) * 8;
     unsigned w[4] = {0u, 0u, 0u, 0u}, wc[4] = {0u, 0u, 0u, 0u};
     if (row < N && c0 < ld) {                                    // ld % 8 == 0: a chunk is all-in or all-out
@@ -817,7 +818,8 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
         if (cen) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float m0 = colsum[c0 + 2 * j] * inv_rows, m1 = colsum[c0 + 2 * j + 1] * inv_rows;
+                const float* cs = colsum + (long long)pl * colsum_stride;
+                const float m0 = cs[c0 + 2 * j] * inv_rows, m1 = cs[c0 + 2 * j + 1] * inv_rows;
                 wc[j] = bf16_rne(v[2 * j] - m0) | (bf16_rne(v[2 * j + 1] - m1) << 16);
             }
         }
@@ -831,8 +833,10 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
 // all rows); what matters numerically is that the bulk of the common component is gone, so a 64-row sample replaces
 // a full pass over the plane.
 __global__ __launch_bounds__(256) void k_colsum_sample(const float* __restrict__ X, long long ld, int N, int C, int nsamp,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, long long x_stride, long long out_stride) {
     __shared__ float sh[4][64];
+    X += (long long)blockIdx.y * x_stride;                        // grid.y = plane (one AGCN call each)
+    out += (long long)blockIdx.y * out_stride;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;       // 64 columns x 4 row lanes: independent loads in flight
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
@@ -841,6 +845,16 @@ __global__ __launch_bounds__(256) void k_colsum_sample(const float* __restrict__
     sh[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) out[c] = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) * ((float)N / (float)nsamp);
+}
+
+// zero the pad rows [N, Kp) of `np` bf16 planes [Kp][ldp] (plane stride PSb): producers that write such planes in place
+// (d-grad in MCRN_BF16 mode) only touch the N data rows
+__global__ void k_zero_pad_rows(uint4* __restrict__ planes, long long psb8, int N, int Kp, int ldp8, long long np) {
+    const long long per = (long long)(Kp - N) * ldp8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * np) return;
+    const long long pl = i / per, q = i - pl * per;
+    planes[pl * psb8 + (long long)N * ldp8 + q] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // One block of the stacked adjacency operand of the propagation GEMM (model/MegaCRN.py:20-25 as ONE product):
