@@ -285,7 +285,9 @@ static int nslab_S(int N) {
     static const int small = getenv("MCRN_NSLAB_S") ? atoi(getenv("MCRN_NSLAB_S")) : 32;
     return N <= 256 ? small : N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
 }
-static const int NSLAB_W = 64;
+static const int NSLAB_W = 64;    // split-K slabs of the deferred weight gradients (wide outputs, reduced by k_wunprep)
+static const int NSLAB_T = 256;   // split-K slabs of the tiny-output, very-long-K products (dWq, dMem, dWp): one tile, so K must fill the chip
+static const int NSLAB_E = 16;    // split-K slabs of dE1 / dE2 (N x D outputs, K = N)
 
 static inline bool ds_small_enabled() {
     static const bool on = !(getenv("MCRN_DS_SMALL") && atoi(getenv("MCRN_DS_SMALL")) == 0);   // default on: 9.9 vs 10.7 ms/step at METR-LA
@@ -681,7 +683,7 @@ static int colsum(const float* X, long long ld, long long rows, int C, float* pa
                   int accumulate, hipStream_t st, int chunk = COLSUM_CHUNK) {
     const int nchunk = cdiv(rows, chunk);
     LAUNCH(k_colsum_stage1, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, X, ld, rows, C, chunk, part);
-    LAUNCH(k_colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, (const float*)part, nchunk, C, out, accumulate);
+    LAUNCH(k_colsum_stage2, dim3(cdiv(C, 64)), dim3(1024), 0, st, (const float*)part, nchunk, C, out, accumulate);
     return 0;
 }
 static size_t colsum_part_floats(long long rows, int C, int chunk = COLSUM_CHUNK) { return (size_t)cdiv(rows, chunk) * C; }
@@ -768,7 +770,7 @@ static int cell_bwd_ca(const Shp& s, const float* dP, const float* dQ, const flo
 }
 
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
-struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
 static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
     o.ldS = ldS;
@@ -778,6 +780,7 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     o.St1 = b.take<float>(nn); o.St2 = b.take<float>(nn);
     o.dLa = b.take<float>(nn); o.dLb = b.take<float>(nn); o.dLs = b.take<float>(nn);
     o.dE1 = b.take<float>(nd); o.dE2 = b.take<float>(nd);
+    o.dE_s = b.take<float>(nd * NSLAB_E);
     for (int i = 0; i < 4; ++i) o.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     o.simg_n = (N + 3) & ~3;
     for (int i = 0; i < 4; ++i) o.simg[i] = N > 256 ? b.take<uint4>(bimg_uint4(N, N)) : nullptr;
@@ -849,7 +852,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
 static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
                         const SupBufs& o, const float* g1, const float* g2, long long ldg,
                         const float* dS1, const float* dS2, long long ldd, int nslab, long long slab,
-                        float* dWe1, float* dWe2, float* dMem_acc, hipStream_t st) {
+                        float* dWe1, float* dWe2, float* dMem_acc, hipStream_t st, int dmem_slabs = 0) {
     if (nslab > 16) {   // 64 per-workgroup slabs of ds_small: fold them 8-wide at full-chip parallelism first (11 MB per support)
         const int groups = 8;
         const long long n = (long long)N * ldd;
@@ -860,21 +863,20 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
     LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, dS1, ldd, nslab, slab, o.dLa, o.ldS, N);
     LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, dS2, ldd, nslab, slab, o.dLb, o.ldS, N);
     CKI(transpose(o.dLs, o.ldS, o.dLb, o.ldS, o.dLa, o.ldS, N, st));   // dLs = dL1 + dL2^T
-    {   // dE1 = dLs E2
+    // dE1 = dLs E2 and dE2 = dLs^T E1: N x D outputs (a few dozen tiles) over K = N: split K into NSLAB_E slabs so that the
+    // launch fills the chip (at N = 1843 a single pass over K took ~80 us per product on 29 workgroups)
+    for (int which = 0; which < 2; ++which) {
+        CK(hipMemsetAsync(o.dE_s, 0, (size_t)NSLAB_E * N * D * sizeof(float), st));
         GemmP p = gp();
         p.M = N; p.N = D; p.K = N;
-        p.A[0] = o.dLs; p.am = plain(o.ldS); p.ak = plain(1);
-        p.B[0] = o.E2; p.bk = plain(D); p.bn = plain(1);
-        p.C[0] = o.dE1; p.cm = plain(D); p.cn = plain(1);
-        CKI(gemm(p, true, false, 0, ROLE_MISC, st));
-    }
-    {   // dE2 = dLs^T E1
-        GemmP p = gp();
-        p.M = N; p.N = D; p.K = N;
-        p.A[0] = o.dLs; p.am = plain(1); p.ak = plain(o.ldS);
-        p.B[0] = o.E1; p.bk = plain(D); p.bn = plain(1);
-        p.C[0] = o.dE2; p.cm = plain(D); p.cn = plain(1);
-        CKI(gemm(p, false, false, 0, ROLE_MISC, st));
+        p.A[0] = o.dLs;
+        if (which == 0) { p.am = plain(o.ldS); p.ak = plain(1); } else { p.am = plain(1); p.ak = plain(o.ldS); }
+        p.B[0] = which ? o.E1 : o.E2; p.bk = plain(D); p.bn = plain(1);
+        p.C[0] = o.dE_s; p.Cin[0] = o.dE_s; p.cm = plain(D); p.cn = plain(1);
+        p.beta = 1.f; p.slab = (long long)N * D;
+        CKI(gemm(p, which == 0, false, NSLAB_E, ROLE_MISC, st));
+        LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * D, 256)), dim3(256), 0, st, which ? o.dE2 : o.dE1, (const float*)o.dE_s, NSLAB_E,
+               (long long)N * D, (long long)N * D, 0);
     }
     for (int i = 0; i < 2; ++i) {
         {   // dWe = dE Mem^T
@@ -891,8 +893,8 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
             p.A[0] = i ? We2 : We1; p.am = plain(1); p.ak = plain(M);
             p.B[0] = i ? o.dE2 : o.dE1; p.bk = plain(D); p.bn = plain(1);
             p.C[0] = dMem_acc; p.Cin[0] = dMem_acc; p.cm = plain(D); p.cn = plain(1);
-            p.beta = 1.f;
-            CKI(gemm(p, false, false, 0, ROLE_MISC, st));
+            p.beta = 1.f; p.slab = (long long)M * D;
+            CKI(gemm(p, false, false, dmem_slabs, ROLE_MISC, st));   // one tile, K = N: spread over the slabs the caller reduces
         }
     }
     return 0;
@@ -1047,9 +1049,9 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.dval = b.take<float>((size_t)R * D);
     P.dsc = b.take<float>((size_t)R * M);
     P.dq = b.take<float>((size_t)R * D);
-    P.dWq_s = b.take<float>((size_t)NSLAB_W * H * D);
-    P.dMem_s = b.take<float>((size_t)NSLAB_W * M * D);
-    P.dWp_s = b.take<float>((size_t)NSLAB_W * od * Hd);
+    P.dWq_s = b.take<float>((size_t)NSLAB_T * H * D);
+    P.dMem_s = b.take<float>((size_t)NSLAB_T * M * D);
+    P.dWp_s = b.take<float>((size_t)NSLAB_T * od * Hd);
     int Tm = d->T_in > d->T_out ? d->T_in : d->T_out;
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
@@ -1229,7 +1231,7 @@ static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long
         p.B[0] = dq; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = dWq_s; p.Cin[0] = dWq_s; p.cm = plain(D); p.cn = plain(1);
         p.beta = 1.f; p.slab = (long long)H * D;
-        CKI(gemm(p, false, false, NSLAB_W, ROLE_MISC, st));
+        CKI(gemm(p, false, false, NSLAB_T, ROLE_MISC, st));
     }
     for (int i = 0; i < 2; ++i) {
         GemmP p = gp();
@@ -1238,7 +1240,7 @@ static int memory_bwd_gemms(const float* h, long long ldh, const float* Wq, long
         p.B[0] = i ? q_rows : dval; p.bk = plain(D); p.bn = plain(1);
         p.C[0] = dMem_s; p.Cin[0] = dMem_s; p.cm = plain(D); p.cn = plain(1);
         p.beta = 1.f; p.slab = (long long)M * D;
-        CKI(gemm(p, false, false, NSLAB_W, ROLE_MISC, st));
+        CKI(gemm(p, false, false, NSLAB_T, ROLE_MISC, st));
     }
     return 0;
 }
@@ -1332,9 +1334,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
     for (int i = 0; i < 4; ++i)
         CK(hipMemsetAsync(P.dWs[i], 0, (size_t)(i < 2 ? se : sd).G * (i < 2 ? se : sd).Cp * Os[i] * NSLAB_W * sizeof(float), st));
-    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
-    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
-    CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_W * od * Hd * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_T * od * Hd * sizeof(float), st));
     if (P.bf16 && P.Kp > N) {   // pad rows of the bf16 gradient planes: d-grad writes the N data rows in place
         for (int e_ = 0; e_ < 2; ++e_) {
             const Shp& s_ = e_ ? sd : se;
@@ -1389,8 +1391,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         q.B[0] = P.Zdec + sd.ZT; q.bk = two((int)R, sd.ZT, sd.Cp); q.bk_hi[0] = sd.ZT; q.bn = plain(1);
         q.C[0] = P.dWp_s; q.Cin[0] = P.dWp_s; q.cm = plain(Hd); q.cn = plain(1);
         q.beta = 1.f; q.slab = (long long)od * Hd;
-        CKI(gemm(q, false, false, NSLAB_W, ROLE_MISC, ws_));
-        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, ws_, g->proj_w, (const float*)P.dWp_s, NSLAB_W,
+        CKI(gemm(q, false, false, NSLAB_T, ROLE_MISC, ws_));
+        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, ws_, g->proj_w, (const float*)P.dWp_s, NSLAB_T,
                (long long)od * Hd, (long long)od * Hd, 0);
         CKI(colsum(P.dgo, od, To * R, od, part_, g->proj_b, 0, ws_));
     }
@@ -1409,7 +1411,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     LAUNCH(k_copy2d, dim3(cdiv(R * H, 256)), dim3(256), 0, st, P.dacc_e, (long long)H, (const float*)P.dacc_d, (long long)Hd, R, H);
     CKI(memory_bwd_gemms(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, R, H, M, D, P.att_rows, P.q_rows, P.dval, P.dsc, P.dq,
                          P.dacc_e, H, true, P.dWq_s, P.dMem_s, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_W,
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_T,
            (long long)H * D, (long long)H * D, 0);
     // ---- encoder BPTT
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
@@ -1444,11 +1446,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(ds_bf16(se, u, P.dPb_e, P.x0c_e, 2 * Ti, P.dA, P.ldS, true, st));
         CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
-                         P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st));
+                         P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
     } else
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
-                     P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_W,
+                     P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_T,
            (long long)M * D, (long long)M * D, 0);
     if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
     if (d_neg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 1, d_neg, B, N, D);
@@ -1540,7 +1542,7 @@ static void plan_mem(int B, int N, int H, int M, int D, char* base, MemPlan& P) 
     P.ind = b.take<int>(R * 2);
     P.dval = b.take<float>(R * D); P.dsc = b.take<float>(R * M); P.dq = b.take<float>(R * D);
     P.dh_rows = b.take<float>(R * H);
-    P.dWq_s = b.take<float>((size_t)NSLAB_W * H * D); P.dMem_s = b.take<float>((size_t)NSLAB_W * M * D);
+    P.dWq_s = b.take<float>((size_t)NSLAB_T * H * D); P.dMem_s = b.take<float>((size_t)NSLAB_T * M * D);
     P.total = (b.off + 255) & ~(size_t)255;
 }
 
@@ -1864,13 +1866,13 @@ int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, cons
     MemPlan P;
     plan_mem(B, N, H, M, D, (char*)ws, P);
     const long long R = (long long)B * N;
-    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_W * H * D * sizeof(float), st));
-    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_W * M * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
+    CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
     CKI(memory_bwd_rows_launch(nullptr, 0, 0, dvalue, dquery, P.att, Mem, B, N, M, D, P.dval, P.dsc, P.dq, st));
     CKI(memory_bwd_gemms(P.h_rows, H, Wq, R, H, M, D, P.att, P.q_rows, P.dval, P.dsc, P.dq, P.dh_rows, H, false,
                          P.dWq_s, P.dMem_s, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, dWq, (const float*)P.dWq_s, NSLAB_W, (long long)H * D, (long long)H * D, 0);
-    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dMem, (const float*)P.dMem_s, NSLAB_W, (long long)M * D, (long long)M * D, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, dWq, (const float*)P.dWq_s, NSLAB_T, (long long)H * D, (long long)H * D, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dMem, (const float*)P.dMem_s, NSLAB_T, (long long)M * D, (long long)M * D, 0);
     if (dpos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 0, dpos, B, N, D);
     if (dneg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 1, dneg, B, N, D);
     return rows_to_bnc(dh, P.dh_rows, H, 0, H, B, N, st);

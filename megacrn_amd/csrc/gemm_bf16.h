@@ -127,6 +127,15 @@ struct Bf16Tile {
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); XCD x gets a contiguous
 // range of tiles (bijective for any tile count), walked GM row tiles per column tile: the tiles resident on one XCD
 // cover a compact patch of C and share A row panels / B column panels in its L2.
+// walk order inside a range of tiles: GM row tiles per column tile
+__device__ __forceinline__ void bf16_tile_coords(int L, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    constexpr int GM = 4;
+    const int width = GM * tiles_n;
+    const int grp = L / width, first_m = grp * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int rr = L - grp * width;
+    tile_m = first_m + rr % gsz; tile_n = rr / gsz;
+}
 __device__ __forceinline__ void bf16_tile_of(const Bf16GemmP& p, int BM, int BN, int& tile_m, int& tile_n) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nblk = tiles_m * tiles_n;
@@ -135,12 +144,7 @@ __device__ __forceinline__ void bf16_tile_of(const Bf16GemmP& p, int BM, int BN,
         const int q = nblk >> 3, r = nblk & 7, x = L & 7, i = L >> 3;
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    constexpr int GM = 4;
-    const int width = GM * tiles_n;
-    const int grp = L / width, first_m = grp * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int rr = L - grp * width;
-    tile_m = first_m + rr % gsz; tile_n = rr / gsz;
+    bf16_tile_coords(L, tiles_m, tiles_n, tile_m, tile_n);
 }
 
 template <int FM, int FN, int BN, int CH, int RP, bool BTR>
@@ -335,20 +339,102 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
 //     phase 2t+1 : G0 compute(t) | G1 load(t)           released by the barrier that ended phase 2t-1)
 // and waits (counted vmcnt) for its share of tile t+1 before the barrier that ends phase 2t+1.
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
-    constexpr int WGM = 2, WGN = 4, NT = 512;
-    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+struct PpLoop {
+    static constexpr int WGM = 2, WGN = 4, NT = 512;
+    static constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
     static_assert(BM % 64 == 0 && BN % 128 == 0, "tile shape");
     using T = Bf16Tile<BM, BN, BK, NT, BTR>;
-    constexpr int KS = T::KS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+    static constexpr int KS = T::KS;
 
+    // acc = sum over the K tiles [kt_beg, kt_beg + nt) of the C tile at (m_blk, n_blk).  Ends with every fragment in
+    // registers; the caller puts a barrier between the use of acc and the next run() (LDS stages are reused).
+    static __device__ __forceinline__ void run(const Bf16GemmP& p, unsigned char* smem, unsigned lds_base, int tid, int wave,
+                                               int m_blk, int n_blk, int kt_beg, int nt, const int (&aoff)[FM],
+                                               const int (&boff)[FN], f32x16_t (&acc)[FM][FN]) {
+        const int grp = wave / WGN;                              // waves 0-3: group 0 (upper half of the tile), 4-7: group 1
+        T tl;
+        tl.init(p, tid, m_blk, n_blk, kt_beg);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+        bf16x8_t fa[FM][KS], fb[FN][KS];
+        auto load_frags = [&](int stg) {
+            const unsigned char* sA = smem + stg * T::STAGE;
+            const unsigned char* sB = sA + T::ASLOTS * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[i][ks] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[j][ks] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+            }
+        };
+        auto compute = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // wait until this wave's share of tile u has landed: issued so far are tiles <= u + NSTAGE - 2
+        auto wait_landed = [&](int u) {
+            if (NSTAGE > 2 && u + NSTAGE - 2 < nt) MCRN_VMCNT((NSTAGE - 2) * T::NLD_MIN);
+            else MCRN_VMCNT(0);
+        };
+
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nt) tl.issue(lds_base, s, wave);
+        wait_landed(0);
+        __syncthreads();
+        int rd = 0, wr = NSTAGE - 1;                             // stage read next / stage the next DMA fills
+        if (grp == 0) {
+            for (int t = 0; t < nt; ++t) {
+                load_frags(rd);                                  // phase 2t
+                if (t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                compute();                                       // phase 2t+1
+                if (t + 1 < nt) wait_landed(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (++rd == NSTAGE) rd = 0;
+            }
+        } else {
+            if (NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }   // phase 0: nothing to compute yet
+            __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                load_frags(rd);                                  // phase 2t+1
+                if (t + 1 < nt) wait_landed(t + 1);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                compute();                                       // phase 2t+2
+                if (t + NSTAGE < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < nt) __syncthreads();
+                if (++rd == NSTAGE) rd = 0;
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
+    using L = PpLoop<BM, BN, BK, NSTAGE, BTR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int grp = wm;                                          // waves 0-3: group 0 (upper half of the tile), 4-7: group 1
+    const int wm = wave / L::WGN, wn = wave % L::WGN;
     int tile_m, tile_n;
     bf16_tile_of(p, BM, BN, tile_m, tile_n);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
@@ -357,84 +443,106 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
     if (kt_beg >= kt_end) return;
-    const int nt = kt_end - kt_beg;
+    int aoff[L::FM], boff[L::FN];
+    bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
+    f32x16_t acc[L::FM][L::FN];
+    L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
+    bf16_epilogue<L::FM, L::FN>(p, acc, split, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
+}
 
-    T tl;
-    tl.init(p, tid, m_blk, n_blk, kt_beg);
+// ---------------------------------------------------------------------------------------------------------
+// Kernel 3, stream-K over the ping-pong loop: ONE workgroup per CU, each takes an equal share of the (tile, K tile)
+// units instead of whole tiles, so a product whose tile count is not a multiple of the CU count (261 tiles of
+// 256 x 256 for the N = 1843 propagation: two rounds, the second 2 % full) or far below it (72 tiles, K = 4 x 1843
+// for its transpose) still keeps every CU busy for the same time.
+//   * the tiles are dealt to the 8 XCDs first (contiguous ranges, as in bf16_tile_of); the 32 workgroups of an XCD
+//     split THAT range's units evenly - all workgroups that share a tile share an L2;
+//   * a workgroup walks its unit range from the top: first the piece that does NOT reach the end of its tile (at most
+//     one): raw accumulators -> its workspace slot, flag = epoch; then whole tiles; last the piece that ends a tile
+//     begun by lower-numbered workgroups: it waits for their flags, adds their partials in a fixed order (bitwise
+//     reproducible) and runs the epilogue.  Waits only ever point at lower blockIdx.x of the same launch, which the
+//     dispatcher started earlier: no deadlock however few workgroups are resident.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
+__global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(const Bf16GemmP p) {
+    using L = PpLoop<BM, BN, BK, NSTAGE, BTR>;
+    constexpr int FM = L::FM, FN = L::FN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
+    const int wm = wave / L::WGN, wn = wave % L::WGN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = tiles_m * tiles_n;
+    const int nkt = p.nseg * p.tps;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, J = gridDim.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int ntx = q + (x < r ? 1 : 0);                          // tiles of this XCD: [tx0, tx0 + ntx)
+    const int tx0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const long long Ux = (long long)ntx * nkt;                    // its units, split evenly over its J workgroups
+    const int u0 = (int)(Ux * j / J), u1 = (int)(Ux * (j + 1) / J);
+
     int aoff[FM], boff[FN];
-    bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
-
+    bf16_frag_offsets<FM, FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int SLOT4 = BM * BN / 4;                            // float4 per workspace slot
+    f32x4_t* __restrict__ ws4 = reinterpret_cast<f32x4_t*>(p.sk_ws);
+    const int frag0 = (wave * (FM * FN * 4)) * 64 + lane;         // slot layout: [wave][fragment][quarter][lane] float4
 
-    bf16x8_t fa[FM][KS], fb[FN][KS];
-    auto load_frags = [&](int stg) {
-        const unsigned char* sA = smem_bf16 + stg * T::STAGE;
-        const unsigned char* sB = sA + T::ASLOTS * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i][ks] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j][ks] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
-        }
-    };
-    auto compute = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+    int u_hi = u1;
+    while (u_hi > u0) {
+        const int t = (u_hi - 1) / nkt, ts = t * nkt;
+        const int lo = max(u0, ts);
+        const bool owner = u_hi - ts == nkt;
+        int tile_m, tile_n;
+        bf16_tile_coords(tx0 + t, tiles_m, tiles_n, tile_m, tile_n);
+        const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+        L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, lo - ts, u_hi - lo, aoff, boff, acc);
+        if (!owner) {
+            f32x4_t* __restrict__ dst = ws4 + (long long)blockIdx.x * SLOT4 + frag0;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // wait until this wave's share of tile u has landed: issued so far are tiles <= u + NSTAGE - 2
-    auto wait_landed = [&](int u) {
-        if (NSTAGE > 2 && u + NSTAGE - 2 < nt) MCRN_VMCNT((NSTAGE - 2) * T::NLD_MIN);
-        else MCRN_VMCNT(0);
-    };
-
+                for (int jn = 0; jn < FN; ++jn)
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nt) tl.issue(lds_base, s, wave);
-    wait_landed(0);
-    __syncthreads();
-    int rd = 0, wr = NSTAGE - 1;                                 // stage read next / stage the next DMA fills
-    if (grp == 0) {
-        for (int t = 0; t < nt; ++t) {
-            load_frags(rd);                                      // phase 2t
-            if (t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x4_t v = {acc[i][jn][4 * qq], acc[i][jn][4 * qq + 1], acc[i][jn][4 * qq + 2], acc[i][jn][4 * qq + 3]};
+                        dst[((i * FN + jn) * 4 + qq) * 64] = v;
+                    }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            compute();                                           // phase 2t+1
-            if (t + 1 < nt) wait_landed(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (++rd == NSTAGE) rd = 0;
+            if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, p.sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lo > ts) {                                        // the tile began in lower-numbered workgroups of this XCD
+                for (int jj = j - 1; jj >= 0; --jj) {
+                    const int a1 = (int)(Ux * (jj + 1) / J);
+                    if (a1 <= ts) break;
+                    if ((int)(Ux * jj / J) == a1) continue;       // (no units: wrote nothing)
+                    const int g2 = (jj << 3) | x;
+                    if (tid == 0)
+                        while (__hip_atomic_load(p.sk_flag + g2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch)
+                            __builtin_amdgcn_s_sleep(2);
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const f32x4_t* __restrict__ src = ws4 + (long long)g2 * SLOT4 + frag0;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const f32x4_t v = src[((i * FN + jn) * 4 + qq) * 64];
+                                acc[i][jn][4 * qq] += v[0]; acc[i][jn][4 * qq + 1] += v[1];
+                                acc[i][jn][4 * qq + 2] += v[2]; acc[i][jn][4 * qq + 3] += v[3];
+                            }
+                }
+            }
+            bf16_epilogue<FM, FN>(p, acc, 0, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
         }
-    } else {
-        if (NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }   // phase 0: nothing to compute yet
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            load_frags(rd);                                      // phase 2t+1
-            if (t + 1 < nt) wait_landed(t + 1);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            compute();                                           // phase 2t+2
-            if (t + NSTAGE < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < nt) __syncthreads();
-            if (++rd == NSTAGE) rd = 0;
-        }
+        __syncthreads();                                          // acc consumed, LDS stages free for the next piece
+        u_hi = lo;
     }
-    bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -480,6 +588,56 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
+// stream-K workspace: one per stream (launches on one stream are ordered; two streams may run two of them at once)
+struct SkWs { float* ws; int* flag; int epoch; int G; };
+static SkWs* sk_workspace(hipStream_t st, hipError_t& err) {
+    static SkWs tab[8];
+    static hipStream_t key[8];
+    static int n = 0;
+    err = hipSuccess;
+    for (int i = 0; i < n; ++i)
+        if (key[i] == st) return &tab[i];
+    if (st == (hipStream_t)-1) {                                  // release request
+        for (int i = 0; i < n; ++i) { (void)hipFree(tab[i].ws); (void)hipFree(tab[i].flag); }
+        n = 0;
+        return nullptr;
+    }
+    if (n == 8) { err = hipErrorOutOfMemory; return nullptr; }
+    int dev = 0, cus = 0;
+    if ((err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
+    if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return nullptr;
+    SkWs w;
+    w.G = cus & ~7; w.epoch = 0;
+    if (w.G < 8) { err = hipErrorInvalidValue; return nullptr; }
+    if ((err = hipMalloc(&w.ws, (size_t)w.G * 256 * 256 * sizeof(float))) != hipSuccess) return nullptr;
+    if ((err = hipMalloc(&w.flag, (size_t)w.G * sizeof(int))) != hipSuccess) return nullptr;
+    if ((err = hipMemsetAsync(w.flag, 0, (size_t)w.G * sizeof(int), st)) != hipSuccess) return nullptr;
+    key[n] = st; tab[n] = w;
+    return &tab[n++];
+}
+void bf16_gemm_release_workspaces() { hipError_t e; (void)sk_workspace((hipStream_t)-1, e); }
+
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
+static inline hipError_t launch_one_bf16_sk(Bf16GemmP p, hipStream_t st) {
+    static_assert(BM * BN <= 256 * 256, "workspace slot");
+    bf16_split_plan(p, BK, 1);
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipError_t e;
+    SkWs* w = sk_workspace(st, e);
+    if (!w) return e;
+    p.sk_ws = w->ws; p.sk_flag = w->flag; p.sk_epoch = ++w->epoch;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(w->G), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
 template <bool BTR, int ROLE>
 static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
@@ -492,7 +650,10 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
         case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong
         case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
         case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
-        default: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);     //  96 KB   1   ping-pong, 64-deep phases
+        case 9: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
+        case 10: return launch_one_bf16_sk<256, 256, 64, 2, BTR, ROLE>(p, st);             // 128 KB   1   stream-K
+        case 11: return launch_one_bf16_sk<256, 128, 64, 2, BTR, ROLE>(p, st);             //  96 KB   1   stream-K
+        default: return launch_one_bf16_sk<192, 256, 64, 2, BTR, ROLE>(p, st);             // 112 KB   1   stream-K
     }
 }
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {

@@ -39,12 +39,20 @@ struct Bf16GemmP {
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
     int xcd;                  // 1: XCD-aware tile order
+    // stream-K configurations only (launch_gemm_bf16 fills them from the per-stream workspace it owns)
+    float* sk_ws;             // one BM x BN fp32 partial tile per workgroup
+    int* sk_flag;             // one word per workgroup: epoch of the partial it last published
+    int sk_epoch;
 };
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st);
-static const int NCFG_BF16 = 10;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
+static const int NCFG_BF16 = 13;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
 static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
-                                           {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1}};
+                                           {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1},
+                                           {256, 256, 1}, {256, 128, 1}, {192, 256, 1}};
+static const int CFG_BF16_SK0 = 10;   // configurations >= this one are stream-K: one output, nsplit is ignored
+// frees the stream-K workspaces (library teardown / tests)
+void bf16_gemm_release_workspaces();
 
 }  // namespace mcrn

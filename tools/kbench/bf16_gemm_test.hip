@@ -91,6 +91,7 @@ int main(int argc, char** argv) {
     double maxerr = 0, maxref = 0, maxerr_b = 0; int rows_checked = 0;
     std::vector<int> rows = {0, 1, 31, 32, 63, 64, 127, 128, 255, 256, M / 2, M - 2, M - 1};
     for (int i = 0; i < 24; ++i) rows.push_back((int)(rng() % M));
+    for (int m = 5; m < M; m += 61) rows.push_back(m);             // every row tile of every configuration
     for (int m : rows) {
         if (m < 0 || m >= M) continue;
         ++rows_checked;
