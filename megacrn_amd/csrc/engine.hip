@@ -24,6 +24,7 @@
 #include "prop_small.h"
 #include "dgrad_stream.h"
 #include "gemm_bf16_api.h"
+#include "wgrad_stream_api.h"
 #include "ops.h"
 
 namespace mcrn {
@@ -178,8 +179,8 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
 // caller has to reason about (every side launch is joined back before the call returns its last kernel).
 struct Side {
     hipStream_t st = nullptr;
-    hipEvent_t ready[2], done[2], join;
-    bool ok = false, pending[2] = {false, false}, any = false;
+    hipEvent_t ready[4], done[4], join;          // plane sets: (update, gate) x (even, odd cell of the BPTT loop)
+    bool ok = false, pending[4] = {false, false, false, false}, any = false;
 };
 static Side g_side;
 static bool g_use_side = true;
@@ -188,7 +189,7 @@ static int side_init() {
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CK(hipStreamCreateWithPriority(&g_side.st, hipStreamNonBlocking, lo));     // lowest priority: fills idle CUs
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         CK(hipEventCreateWithFlags(&g_side.ready[i], hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming));
     }
@@ -208,13 +209,17 @@ static int side_join(hipStream_t st) {
     if (g_side.ok && g_side.any) {
         CK(hipEventRecord(g_side.join, g_side.st));
         CK(hipStreamWaitEvent(st, g_side.join, 0));
-        g_side.any = false; g_side.pending[0] = g_side.pending[1] = false;
+        g_side.any = false;
+        for (int i = 0; i < 4; ++i) g_side.pending[i] = false;
     }
     return 0;
 }
 
 // error paths: forget pending fork/join state (the caller's next call starts clean)
-static void side_reset() { g_side.any = false; g_side.pending[0] = g_side.pending[1] = false; }
+static void side_reset() {
+    g_side.any = false;
+    for (int i = 0; i < 4; ++i) g_side.pending[i] = false;
+}
 // The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
 // thread per process (the launch model of bench.py / megacrn_amd.train: one process per GPU).
 struct PrecisionScope {
@@ -285,7 +290,8 @@ static int nslab_S(int N) {
     static const int small = getenv("MCRN_NSLAB_S") ? atoi(getenv("MCRN_NSLAB_S")) : 32;
     return N <= 256 ? small : N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
 }
-static const int NSLAB_W = 64;    // split-K slabs of the deferred weight gradients (wide outputs, reduced by k_wunprep)
+static const int NSLAB_W = 256;   // slab capacity of the deferred weight gradients (reduced by k_wunprep)
+static const int NSLAB_W_GEMM = 64;   // ... slabs the tiled-GEMM fallback splits K into
 static const int NSLAB_T = 256;   // split-K slabs of the tiny-output, very-long-K products (dWq, dMem, dWp): one tile, so K must fill the chip
 static const int NSLAB_E = 16;    // split-K slabs of dE1 / dE2 (N x D outputs, K = N)
 
@@ -316,9 +322,9 @@ static std::map<Bf16Key, int> g_tuned_bf16;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
-    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8};
+    static const double eff[CFG_BF16_SK0] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8};
     int best = 0; double bt = 1e300;
-    for (int c = 0; c < NCFG_BF16; ++c) {
+    for (int c = 0; c < CFG_BF16_SK0; ++c) {
         const int per_cu = kCfgBf16[c][2];
         const long long tiles = (long long)cdiv(p.M, kCfgBf16[c][0]) * cdiv(p.N, kCfgBf16[c][1]) * nsplit;
         const double rounds = ceil((double)tiles / (256.0 * per_cu));
@@ -341,10 +347,10 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                 CK(hipEventCreate(&g_tune_ev[1]));
                 g_tune_ev_ok = true;
             }
-            float best_ms = 1e30f, cfg_ms[NCFG_BF16];
-            for (int c = 0; c < NCFG_BF16; ++c) cfg_ms[c] = 1e30f;
+            float best_ms = 1e30f, cfg_ms[CFG_BF16_SK0];
+            for (int c = 0; c < CFG_BF16_SK0; ++c) cfg_ms[c] = 1e30f;
             for (int round = 0; round < 3; ++round)              // min over 3 rounds of 5 launches: robust to clock / cache noise
-                for (int c = 0; c < NCFG_BF16; ++c) {
+                for (int c = 0; c < CFG_BF16_SK0; ++c) {
                     CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));                   // warm-up
                     CK(hipEventRecord(g_tune_ev[0], st));
                     for (int r = 0; r < 5; ++r) CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));
@@ -354,12 +360,12 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                     CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
                     if (ms < cfg_ms[c]) cfg_ms[c] = ms;
                 }
-            for (int c = 0; c < NCFG_BF16; ++c)
+            for (int c = 0; c < CFG_BF16_SK0; ++c)
                 if (cfg_ms[c] < best_ms) { best_ms = cfg_ms[c]; cfg = c; }
             if (getenv("MCRN_TUNE_LOG")) {
                 fprintf(stderr, "[mcrn tune] bf16 %s role %d M=%d N=%d K=%dx%d split=%d:", btr ? "nn" : "nt", role, p.M, p.N, p.nseg,
                         p.seg_len, nsplit);
-                for (int c = 0; c < NCFG_BF16; ++c) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
+                for (int c = 0; c < CFG_BF16_SK0; ++c) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
                 fprintf(stderr, " -> %d\n", cfg);
             }
             g_tuned_bf16[key] = cfg;
@@ -412,7 +418,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
     int nsplit = 1;
     static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 2;
-    if (dT && used_dT && split_env == 2 && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
+    if (dT && used_dT && split_env == 2 && g_force_cfg_bf16 < CFG_BF16_SK0 && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
         nsplit = 2; p.slab = dT - dP; p.cin_first_only = 1;
         *used_dT = true;
     }
@@ -597,7 +603,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             if (side) {
                 const int nb_ = cell_ds ? 2 : 1;          // a merged launch reads the plane sets of both calls
                 for (int i = 0; i < nb_; ++i) {
-                    const int bi = cell_ds ? i : buf;
+                    const int bi = cell_ds ? (buf & ~1) + i : buf;
                     CK(hipEventRecord(g_side.done[bi], g_side.st));
                     g_side.pending[bi] = true;
                 }
@@ -666,8 +672,30 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
 }
 
 // ---- deferred weight gradient: slabs += X_all^T dY_all over T steps -------------------------------
+// The streaming kernel (wgrad_stream.h) takes every shape of the library's bf16x3 sessions; exact-fp32 sessions and odd
+// widths keep the tiled GEMM.  Returns the number of slabs written through *nslab.
+static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* dYall, long long step_stride) {
+    static const bool off = getenv("MCRN_WGRAD_STREAM") && atoi(getenv("MCRN_WGRAD_STREAM")) == 0;
+    return !off && g_precision == MCRN_BF16X3 && wgrad_stream_ok(s.G, s.Cp, O) && aligned16(Xall) && aligned16(dYall) &&
+           ((step_stride | s.PS) & 3) == 0;
+}
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
-                      int O, float* slabs, hipStream_t st) {
+                      int O, float* slabs, hipStream_t st, int* nslab) {
+    if (wgrad_streams(s, O, Xall, dYall, step_stride)) {
+        WgradP q;
+        q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
+        q.dY = dYall; q.O = O; q.slabs = slabs;
+        q.cpt = NSLAB_W / T < 1 ? 1 : NSLAB_W / T;
+        if (q.cpt > cdiv(s.R, 32)) q.cpt = (int)cdiv(s.R, 32);
+        q.kch = (int)(cdiv(cdiv(s.R, q.cpt), 32) * 32);
+        if (T * q.cpt > NSLAB_W) FAIL("weight gradient: %d steps exceed the slab capacity", T);
+        *nslab = T * q.cpt;
+        const double fl = 2.0 * (double)s.G * s.Cp * O * (double)T * (double)s.R;
+        MCRN_PROF_WRAP(ROLE_WGRAD, launch_wgrad_stream(q, st), fl, 2.0 * (double)s.G * s.C * O * (double)T * (double)s.R);
+        return 0;
+    }
+    *nslab = NSLAB_W_GEMM;
+    CK(hipMemsetAsync(slabs, 0, (size_t)s.G * s.Cp * O * NSLAB_W_GEMM * sizeof(float), st));
     GemmP p = gp();
     p.M = s.G * s.Cp; p.N = O; p.K = (int)(T * s.R);
     p.A[0] = Xall; p.am = two(s.Cp, s.PS, 1);
@@ -675,7 +703,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
     p.B[0] = dYall; p.bk = plain(O); p.bn = plain(1);
     p.C[0] = slabs; p.Cin[0] = slabs; p.cm = plain(O); p.cn = plain(1);
     p.beta = 1.f; p.slab = (long long)s.G * s.Cp * O;
-    return gemm(p, false, false, NSLAB_W, ROLE_WGRAD, st);
+    return gemm(p, false, false, NSLAB_W_GEMM, ROLE_WGRAD, st);
 }
 
 static const int COLSUM_CHUNK = 512;
@@ -739,19 +767,21 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
                          float* dTg = nullptr, bool do_a = true, bool do_c = true, bool* xu_out = nullptr,
-                         bool* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */) {
+                         bool* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */,
+                         int pair = 0 /* which (dP, dQ) plane-set pair the caller handed in: event slots 2*pair, 2*pair+1 */) {
     const long long RH = s.R * s.H;
     bool xu = false, xg = false;
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     DsP cell_ds;
     cell_ds.nseg = 0;
-    // opt-in (measured slower at METR-LA: 8.82 vs 7.58 ms per step - the 68 us merged launch holds BOTH plane sets and
-    // the main queue waits for it; the per-call launches of 41 us release them one at a time)
+    // MCRN_DS_MERGE=1: the two AGCN calls of a cell share one adjacency-gradient launch (slab read and written once per
+    // cell).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the merged launch holds both sets
+    // and the main queue waited for it); cells now alternate between two pairs.
     static const bool merge_ds = getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 1;
     DsP* cds = merge_ds ? &cell_ds : nullptr;
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 0, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 1, w.id_g, dTg, &xg, dPb, cds, true));
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true));
     if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
@@ -937,9 +967,9 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
     }
     return 0;
 }
-static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st) {
+static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st, int nslab) {
     long long tot = (long long)2 * s.K * s.C * O;
-    LAUNCH(k_wunprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, dW, slabs, NSLAB_W, (long long)s.G * s.Cp * O, s.d, s.H, s.Cp, s.K, O);
+    LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, (long long)s.G * s.Cp * O, s.d, s.H, s.Cp, s.K, O);
     return 0;
 }
 
@@ -958,6 +988,7 @@ struct ModelPlan {
     float *Zdec, *Ydec, *zr_d, *hc_d;
     float *q_rows, *att_rows; int* ind_rows;
     float *dP, *dQ, *dTu, *dTg;
+    float *dP2, *dQ2;              // second plane-set pair: cells alternate, so the helper stream may lag one cell behind
     float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
     float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
     bool defer_ds;
@@ -1029,6 +1060,8 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     size_t zmax = (size_t)(P.se.ZT > P.sd.ZT ? P.se.ZT : P.sd.ZT);
     P.dP = b.take<float>(zmax);
     P.dQ = b.take<float>(zmax);
+    P.dP2 = b.take<float>(zmax);
+    P.dQ2 = b.take<float>(zmax);
     {
         size_t pmax = (size_t)(P.se.PS > P.sd.PS ? P.se.PS : P.sd.PS);
         P.dTu = b.take<float>(pmax);
@@ -1330,10 +1363,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
     Sup u = model_sup(P, N);
-    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
-    for (int i = 0; i < 4; ++i)
-        CK(hipMemsetAsync(P.dWs[i], 0, (size_t)(i < 2 ? se : sd).G * (i < 2 ? se : sd).Cp * Os[i] * NSLAB_W * sizeof(float), st));
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_T * od * Hd * sizeof(float), st));
@@ -1354,8 +1384,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         for (int t = To - 1; t >= 0; --t) {
             const bool last = t == To - 1;
             const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
-            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dP;
-            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQ;
+            const int pair = t & 1;
+            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : (pair ? P.dP2 : P.dP);
+            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : (pair ? P.dQ2 : P.dQ);
             if (last) {
                 LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
                        (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
@@ -1369,7 +1400,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
                               P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PSb : nullptr));
+                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PSb : nullptr, pair));
             dPprev = dPt; dQprev = dQt;
         }
     }
@@ -1400,10 +1431,12 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         hipStream_t st = ws_;
         CKI(ds_deferred(P, sd, To, P.dPall_d, P.Ydec, P.Zdec, 0, N, st));
     }
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_));
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_));
-    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_));
-    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_));
+    int ns1 = 0;
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1));
+    int ns2 = 0;
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2));
+    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1));
+    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2));
     CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
     CKI(colsum(P.dU_d, Hd, To * R, Hd, part_, g->dec_update_b, 0, ws_));
     // ---- memory head backward: dacc_d = d[h_t | value]
@@ -1419,20 +1452,25 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         bool xu = false, xg = false;
         for (int t = Ti - 1; t >= 0; --t) {
             const bool first = t == Ti - 1;
+            const int pair = t & 1;
+            float* dPt = pair ? P.dP2 : P.dP;
+            float* dQt = pair ? P.dQ2 : P.dQ;
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
-                CKI(cell_bwd_ca(se, P.dP, P.dQ, P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
+                CKI(cell_bwd_ca(se, pair ? P.dP : P.dP2, pair ? P.dQ : P.dQ2, P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
                                 P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
                                 P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
-                              P.dP, P.dQ, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PSb : nullptr));
+                              dPt, dQt, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
+                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PSb : nullptr, pair));
         }
     }
-    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st));
-    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st));
-    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st));
-    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st));
+    int ns3 = 0;
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3));
+    int ns4 = 0;
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4));
+    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st, ns3));
+    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st, ns4));
     CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
     CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
     // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
@@ -1761,12 +1799,12 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
-    CK(hipMemsetAsync(P.dWs, 0, (size_t)s.G * s.Cp * O * NSLAB_W * sizeof(float), st));
     CKI(bnc_to_rows(P.dY, O, 0, O, dy, B, N, st));
     CKI(agcn_bwd_core(s, u, P.dY, O, P.Wd, P.Z, P.dP, st));
     CKI(side_join(st));
-    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dY, O, P.dWs, st));
-    CKI(wunprep(dW, P.dWs, s, O, st));
+    int ns5 = 0;
+    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dY, O, P.dWs, st, &ns5));
+    CKI(wunprep(dW, P.dWs, s, O, st, ns5));
     CKI(colsum(P.dY, O, s.R, O, P.part, db, 0, st));
     CKI(rows_to_bnc(dx, P.dP, s.Cp, 0, C, B, N, st));
     LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
@@ -1819,16 +1857,16 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
-    CK(hipMemsetAsync(P.dWs[0], 0, (size_t)s.G * s.Cp * 2 * H * NSLAB_W * sizeof(float), st));
-    CK(hipMemsetAsync(P.dWs[1], 0, (size_t)s.G * s.Cp * H * NSLAB_W * sizeof(float), st));
     CKI(bnc_to_rows(P.dacc, H, 0, H, dhn, B, N, st));
     CellW w{P.Wf[0], P.Wd[0], nullptr, P.Wf[1], P.Wd[1], nullptr};
     CKI(cell_bwd_core(s, u, P.Z, P.Y, P.zr, P.hc, w, P.dacc, P.dU, P.dG, P.dP, P.dQ, P.dacc, P.dxin, st, P.dTu, P.dTg));
     CKI(side_join(st));
-    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dG, 2 * H, P.dWs[0], st));
-    CKI(agcn_wgrad(s, P.Y, s.ZT, 1, P.dU, H, P.dWs[1], st));
-    CKI(wunprep(dgate_w, P.dWs[0], s, 2 * H, st));
-    CKI(wunprep(dupdate_w, P.dWs[1], s, H, st));
+    int ns6 = 0;
+    CKI(agcn_wgrad(s, P.Z, s.ZT, 1, P.dG, 2 * H, P.dWs[0], st, &ns6));
+    int ns7 = 0;
+    CKI(agcn_wgrad(s, P.Y, s.ZT, 1, P.dU, H, P.dWs[1], st, &ns7));
+    CKI(wunprep(dgate_w, P.dWs[0], s, 2 * H, st, ns6));
+    CKI(wunprep(dupdate_w, P.dWs[1], s, H, st, ns7));
     CKI(colsum(P.dG, 2 * H, s.R, 2 * H, P.part, dgate_b, 0, st));
     CKI(colsum(P.dU, H, s.R, H, P.part, dupdate_b, 0, st));
     CKI(rows_to_bnc(dh, P.dacc, H, 0, H, B, N, st));

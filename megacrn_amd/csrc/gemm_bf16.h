@@ -488,10 +488,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(const Bf16GemmP p) {
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     constexpr int SLOT4 = BM * BN / 4;                            // float4 per workspace slot
     f32x4_t* __restrict__ ws4 = reinterpret_cast<f32x4_t*>(p.sk_ws);
-    const int frag0 = (wave * (FM * FN * 4)) * 64 + lane;         // slot layout: [wave][fragment][quarter][lane] float4
 
     int u_hi = u1;
     while (u_hi > u0) {
+        // The K loop uses every VGPR.  Whatever the epilogue / fix-up derive from the lane id must be formed AFTER it,
+        // per piece: an opaque copy keeps the compiler from hoisting ~200 address registers out of this loop into
+        // scratch (and a launch with that much scratch costs tens of microseconds in the runtime).
+        int lane_p = tid & 63;
+        asm volatile("" : "+v"(lane_p));
+        const int frag0 = (wave * (FM * FN * 4)) * 64 + lane_p;   // slot layout: [wave][fragment][quarter][lane] float4
         const int t = (u_hi - 1) / nkt, ts = t * nkt;
         const int lo = max(u0, ts);
         const bool owner = u_hi - ts == nkt;
@@ -500,19 +505,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(const Bf16GemmP p) {
         const int m_blk = tile_m * BM, n_blk = tile_n * BN;
         L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, lo - ts, u_hi - lo, aoff, boff, acc);
         if (!owner) {
-            f32x4_t* __restrict__ dst = ws4 + (long long)blockIdx.x * SLOT4 + frag0;
+            // partial tile -> workspace with agent-scope (sc1) stores: written through to the memory side, visible to
+            // every XCD without flushing this XCD's whole L2 (what a release fence would do)
+            f32x4_t* dst = ws4 + (long long)blockIdx.x * SLOT4 + frag0;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < FN; ++jn)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const f32x4_t v = {acc[i][jn][4 * qq], acc[i][jn][4 * qq + 1], acc[i][jn][4 * qq + 2], acc[i][jn][4 * qq + 3]};
-                        dst[((i * FN + jn) * 4 + qq) * 64] = v;
-                    }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                for (int jn = 0; jn < FN; ++jn) {
+                    f32x4_t* d = dst + (i * FN + jn) * 4 * 64;
+                    const f32x4_t v0 = {acc[i][jn][0], acc[i][jn][1], acc[i][jn][2], acc[i][jn][3]};
+                    const f32x4_t v1 = {acc[i][jn][4], acc[i][jn][5], acc[i][jn][6], acc[i][jn][7]};
+                    const f32x4_t v2 = {acc[i][jn][8], acc[i][jn][9], acc[i][jn][10], acc[i][jn][11]};
+                    const f32x4_t v3 = {acc[i][jn][12], acc[i][jn][13], acc[i][jn][14], acc[i][jn][15]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                                 "global_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
+                                 "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\t"
+                                 "global_store_dwordx4 %0, %4, off offset:3072 sc1"
+                                 :: "v"(d), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
+                }
+            MCRN_VMCNT(0);
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, p.sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (lo > ts) {                                        // the tile began in lower-numbered workgroups of this XCD
                 for (int jj = j - 1; jj >= 0; --jj) {
@@ -521,24 +534,41 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(const Bf16GemmP p) {
                     if ((int)(Ux * jj / J) == a1) continue;       // (no units: wrote nothing)
                     const int g2 = (jj << 3) | x;
                     if (tid == 0)
-                        while (__hip_atomic_load(p.sk_flag + g2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch)
+                        while (__hip_atomic_load(p.sk_flag + g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch)
                             __builtin_amdgcn_s_sleep(2);
                     __syncthreads();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const f32x4_t* __restrict__ src = ws4 + (long long)g2 * SLOT4 + frag0;
+                    // agent-scope (sc1) loads: never served from a stale line of this XCD's L2, no cache invalidate
+                    const f32x4_t* src = ws4 + (long long)g2 * SLOT4 + frag0;
 #pragma unroll
-                    for (int i = 0; i < FM; ++i)
+                    for (int i = 0; i < FM; ++i) {
+                        f32x4_t v[FN][4];
+#pragma unroll
+                        for (int jn = 0; jn < FN; ++jn) {
+                            const f32x4_t* q4 = src + (i * FN + jn) * 4 * 64;
+                            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                         "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                                         "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                                         "global_load_dwordx4 %3, %4, off offset:3072 sc1"
+                                         : "=&v"(v[jn][0]), "=&v"(v[jn][1]), "=&v"(v[jn][2]), "=&v"(v[jn][3]) : "v"(q4) : "memory");
+                        }
+                        // the wait names every destination, so no use can be scheduled in front of it
+                        static_assert(FN == 2 || FN == 1, "operand list below");
+                        if constexpr (FN == 2)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
+                                         "+v"(v[FN - 1][0]), "+v"(v[FN - 1][1]), "+v"(v[FN - 1][2]), "+v"(v[FN - 1][3]) :: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) :: "memory");
 #pragma unroll
                         for (int jn = 0; jn < FN; ++jn)
 #pragma unroll
                             for (int qq = 0; qq < 4; ++qq) {
-                                const f32x4_t v = src[((i * FN + jn) * 4 + qq) * 64];
-                                acc[i][jn][4 * qq] += v[0]; acc[i][jn][4 * qq + 1] += v[1];
-                                acc[i][jn][4 * qq + 2] += v[2]; acc[i][jn][4 * qq + 3] += v[3];
+                                acc[i][jn][4 * qq] += v[jn][qq][0]; acc[i][jn][4 * qq + 1] += v[jn][qq][1];
+                                acc[i][jn][4 * qq + 2] += v[jn][qq][2]; acc[i][jn][4 * qq + 3] += v[jn][qq][3];
                             }
+                    }
                 }
             }
-            bf16_epilogue<FM, FN>(p, acc, 0, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
+            bf16_epilogue<FM, FN>(p, acc, 0, m_blk + wm * L::WM, n_blk + wn * L::WN, lane_p);
         }
         __syncthreads();                                          // acc consumed, LDS stages free for the next piece
         u_hi = lo;

@@ -51,7 +51,11 @@ static const int NCFG_BF16 = 13;   // {BM, BN, workgroups per CU}: see launch_cf
 static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
                                            {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1},
                                            {256, 256, 1}, {256, 128, 1}, {192, 256, 1}};
-static const int CFG_BF16_SK0 = 10;   // configurations >= this one are stream-K: one output, nsplit is ignored
+// Configurations >= CFG_BF16_SK0 are stream-K (one output, nsplit ignored).  They are NOT in the tuner's candidate set:
+// measured (profiles/r2/kbench_streamk.txt) they only tie the best ping-pong configuration on the N = 1843 products -
+// the fp32 partial tiles have to cross XCDs through the memory side (256 KB written + read per workgroup, ~25 us of a
+// ~55 us ideal) - so they stay an opt-in (MCRN_BF16_CFG=10..12) and a harness case.
+static const int CFG_BF16_SK0 = 10;
 // frees the stream-K workspaces (library teardown / tests)
 void bf16_gemm_release_workspaces();
 

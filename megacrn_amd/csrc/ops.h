@@ -117,23 +117,35 @@ __global__ void k_wprep(const float* __restrict__ W, float* __restrict__ Wf, flo
     Wd[i] = wd;
 }
 
-// dW (reference layout) = sum over slabs of dW' (internal layout), identity plane copied to both supports
-__global__ void k_wunprep(float* __restrict__ dW, const float* __restrict__ slabs, int nslab,
-                          long long slab, int d, int H, int Cp, int K, int O) {
+// dW (reference layout) = sum over slabs of dW' (internal layout), identity plane copied to both supports.
+// 1024 threads = 64 consecutive outputs x 16 slab lanes (up to 256 slabs from the streaming weight-gradient kernel: one
+// thread walking them serially made this a 20 us tail); lane partials are added in a fixed order.
+__global__ __launch_bounds__(1024) void k_wunprep(float* __restrict__ dW, const float* __restrict__ slabs, int nslab,
+                                                  long long slab, int d, int H, int Cp, int K, int O) {
+    __shared__ float sh[16][64];
     const int C = d + H;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long tot = (long long)2 * K * C * O;
-    if (i >= tot) return;
-    int o = (int)(i % O);
-    int q = (int)(i / O);
-    int cref = q % C, kg = q / C;
-    int s = kg / K, k = kg % K;
-    int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
-    int cp = cref < d ? H + cref : cref - d;
-    long long src = ((long long)g * Cp + cp) * O + o;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + el;
+    const long long tot = (long long)2 * K * C * O;
     float v = 0.f;
-    for (int z = 0; z < nslab; ++z) v += slabs[z * slab + src];
-    dW[i] = v;
+    if (i < tot) {
+        int o = (int)(i % O);
+        int q = (int)(i / O);
+        int cref = q % C, kg = q / C;
+        int s = kg / K, k = kg % K;
+        int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
+        int cp = cref < d ? H + cref : cref - d;
+        const float* src = slabs + ((long long)g * Cp + cp) * O + o;
+        for (int z = zl; z < nslab; z += 16) v += src[z * slab];
+    }
+    sh[zl][el] = v;
+    __syncthreads();
+    if (zl == 0 && i < tot) {
+        float t = 0.f;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) t += sh[z][el];
+        dW[i] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

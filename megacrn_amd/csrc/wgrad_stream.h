@@ -1,0 +1,240 @@
+// wgrad_stream.h - weight gradient of the AGCN weight pool as a STREAMING product (gfx950).
+//
+//   dW'[(g, c)][o] = sum over every step t and row r = (n, b) of  X_t[g][r][c] * dY_t[r][o]        (model/MegaCRN.py:26-28)
+//
+// The output is tiny (G*Cp x O: 340 x 128 at METR-LA) and K = T*N*B is enormous (159 000 ... 354 000 rows): every byte of
+// X and dY is needed exactly once, so the floor is the HBM read of the two operands (~300 MB, ~40 us at 8 TB/s).  The
+// tiled GEMM this replaces (gemm_bf16x3.h, 64 split-K slabs) spent half of each workgroup's time converting and storing
+// operand tiles that it then re-read through L2 several times (374 us, 490-700 MB fetched per launch, profiles/r1).
+//
+// Here ONE workgroup owns the whole output block (up to 384 x 128) and a contiguous run of rows; it
+//   * reads 32 rows per stage straight from the planes with 16-byte loads (rows of a plane are contiguous: a stage is
+//     G + 1 contiguous blocks), prefetched one stage ahead into registers;
+//   * splits every value into bf16 hi + lo (the library's bf16x3 arithmetic) and writes both to LDS as [4 k][16 col]
+//     blocks, the layout ds_read_b64_tr_b16 turns into MFMA fragments for BOTH operands - X is used "transposed"
+//     (its columns are the rows of dW') without ever being transposed in memory;
+//   * accumulates hi*hi + hi*lo + lo*hi in fp32 and writes its partial block to slab z; k_wunprep adds the slabs in a
+//     fixed order (bitwise reproducible) while it maps them to the reference layout.
+// One barrier per stage, two LDS stages, no operand byte read twice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "wgrad_stream_api.h"
+
+namespace mcrn {
+
+namespace wgs {
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 4 fp32 -> 4 bf16 hi (8 bytes) + 4 bf16 lo (8 bytes), round-to-nearest-even twice
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    const unsigned h01 = pk_bf16(v.x, v.y), h23 = pk_bf16(v.z, v.w);
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(pk_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u)),
+                    pk_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u)));
+}
+// MFMA operand (8 consecutive k of column col0 + (lane & 31)) of k-step ks from an image of [4 k][16 col] blocks
+template <int W>
+__device__ __forceinline__ bf16x8_t frag(const unsigned char* img, int off, int ks) {
+    const unsigned char* q = img + off + (4 * ks) * (W / 16) * 128;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + (W / 16) * 128));
+    const s16x8_t w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+}  // namespace wgs
+
+// 8 waves = WM x WN; a wave owns MFW x NFW fragments of 32 x 32: output block (32 MFW WM) x (32 NFW WN)
+template <int MFW, int NFW, int WN>
+__global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
+    using namespace wgs;
+    constexpr int WM = 8 / WN;
+    constexpr int MB = 32 * MFW * WM, NB = 32 * NFW * WN;
+    constexpr int CGA = MB / 64, CGB = (NB + 63) / 64;          // 64-column groups a wave stages per operand
+    constexpr int WA = 64 * CGA, WB = 64 * CGB;                 // image widths
+    static_assert(MB % 64 == 0, "row block");
+    constexpr int IMG_A = 32 * WA * 2, IMG_B = 32 * WB * 2;     // bytes of one hi (or lo) image of a 32-row stage
+    constexpr int STAGE = 2 * (IMG_A + IMG_B);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int M = p.G * p.Cp;
+    // grid: y = row chunk, x = (row block, column block) of the output - the workgroups that re-read a chunk (outputs
+    // larger than one block: M > 384 or O > 128) are dispatched together and meet in the memory-side cache
+    const int chunk = blockIdx.y;
+    const int t = chunk / p.cpt, cj = chunk - t * p.cpt;
+    const long long r0 = (long long)cj * p.kch;
+    const long long r1 = min(p.R, r0 + p.kch);
+    const int nrow = r1 > r0 ? (int)(r1 - r0) : 0;
+    const int nit = (nrow + 31) / 32;
+    const int nmb = (M + MB - 1) / MB;
+    const int m0 = (blockIdx.x % nmb) * MB, n0 = (blockIdx.x / nmb) * NB;
+
+    // ---- what this thread stages: row 4w + (lane >> 4) of every 32-row stage, columns 64 j + 4 (lane & 15)
+    const int srow = 4 * w + (lane >> 4), c4 = lane & 15;
+    unsigned offA[CGA], offB[CGB];
+    bool okA[CGA], okB[CGB];
+#pragma unroll
+    for (int j = 0; j < CGA; ++j) {
+        const int m = m0 + 64 * j + 4 * c4;
+        okA[j] = m < M;
+        const int mc = okA[j] ? m : 0;
+        const int g = mc / p.Cp;
+        offA[j] = (unsigned)((long long)g * p.PS + (mc - g * p.Cp));
+    }
+#pragma unroll
+    for (int j = 0; j < CGB; ++j) {
+        const int n = n0 + 64 * j + 4 * c4;
+        okB[j] = n < p.O && 64 * j + 4 * c4 < NB;
+        offB[j] = okB[j] ? (unsigned)n : 0u;
+    }
+    const float* __restrict__ Xt = p.X + (long long)t * p.step_stride + r0 * p.Cp;
+    const float* __restrict__ Yt = p.dY + ((long long)t * p.R + r0) * p.O;
+    // LDS byte offset of this thread's 8 bytes inside an image: block (k / 4 = w, col / 16), row lane >> 4, 4 columns
+    const int wofs = (lane >> 4) * 32 + (c4 & 3) * 8 + (c4 >> 2) * 128;
+
+    float4 va[CGA], vb[CGB];
+    auto fetch = [&](int it) {
+        const int r = 32 * it + srow;
+        const bool ok = r < nrow;
+        const int rc = ok ? r : 0;
+#pragma unroll
+        for (int j = 0; j < CGA; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(Xt + (long long)rc * p.Cp + offA[j]);
+            const bool k = ok && okA[j];
+            va[j] = make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < CGB; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(Yt + (long long)rc * p.O + offB[j]);
+            const bool k = ok && okB[j];
+            vb[j] = make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned char* sA = smem_wg + buf * STAGE;               // [A hi | A lo | B hi | B lo]
+        unsigned char* sB = sA + 2 * IMG_A;
+#pragma unroll
+        for (int j = 0; j < CGA; ++j) {
+            uint2 h, l;
+            split4(va[j], h, l);
+            const int o = (w * (WA / 16) + 4 * j) * 128 + wofs;
+            *reinterpret_cast<uint2*>(sA + o) = h;
+            *reinterpret_cast<uint2*>(sA + IMG_A + o) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < CGB; ++j) {
+            uint2 h, l;
+            split4(vb[j], h, l);
+            const int o = (w * (WB / 16) + 4 * j) * 128 + wofs;
+            *reinterpret_cast<uint2*>(sB + o) = h;
+            *reinterpret_cast<uint2*>(sB + IMG_B + o) = l;
+        }
+    };
+
+    // fragment read offsets (see wgs::frag): lane group g = lane >> 4 picks the k half (g >> 1) and the column half (g & 1)
+    const int gq = lane >> 4, li = lane & 15;
+    const int lofs = (li >> 2) * 32 + (li & 3) * 8;
+    int aoff[MFW], boff[NFW];
+#pragma unroll
+    for (int i = 0; i < MFW; ++i) aoff[i] = ((2 * (gq >> 1)) * (WA / 16) + (wm * MFW + i) * 2 + (gq & 1)) * 128 + lofs;
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) boff[j] = ((2 * (gq >> 1)) * (WB / 16) + (wn * NFW + j) * 2 + (gq & 1)) * 128 + lofs;
+
+    f32x16_t acc[MFW][NFW];
+#pragma unroll
+    for (int i = 0; i < MFW; ++i)
+#pragma unroll
+        for (int j = 0; j < NFW; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    if (nit > 0) fetch(0);
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        stash(buf);
+        if (it + 1 < nit) fetch(it + 1);                         // in flight during the MFMAs below
+        __syncthreads();   // stage `it` visible; every wave is done with the MFMAs of stage it-1, so buf^1 may be rewritten next
+        const unsigned char* sA = smem_wg + buf * STAGE;
+        const unsigned char* sB = sA + 2 * IMG_A;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t ah[MFW], al[MFW], bh[NFW], bl[NFW];
+#pragma unroll
+            for (int i = 0; i < MFW; ++i) { ah[i] = frag<WA>(sA, aoff[i], ks); al[i] = frag<WA>(sA + IMG_A, aoff[i], ks); }
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) { bh[j] = frag<WB>(sB, boff[j], ks); bl[j] = frag<WB>(sB + IMG_B, boff[j], ks); }
+#pragma unroll
+            for (int i = 0; i < MFW; ++i)
+#pragma unroll
+                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MFW; ++i)
+#pragma unroll
+                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MFW; ++i)
+#pragma unroll
+                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // partial block -> slab of this chunk.  C/D layout: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+    float* __restrict__ S = p.slabs + (long long)chunk * M * p.O;
+    const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MFW; ++i)
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) {
+            const int n = n0 + (wn * NFW + j) * 32 + l31;
+            const int mb = m0 + (wm * MFW + i) * 32 + 4 * kq;
+            if (n < p.O) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    if (m < M) S[(long long)m * p.O + n] = acc[i][j][v];
+                }
+            }
+        }
+}
+
+bool wgrad_stream_ok(int G, int Cp, int O) { return O >= 4 && O <= 512 && (O & 3) == 0 && (Cp & 3) == 0 && G >= 1; }
+
+template <int MFW, int NFW, int WN>
+static inline hipError_t launch_wgrad_one(const WgradP& p, hipStream_t st) {
+    constexpr int WM = 8 / WN, MB = 32 * MFW * WM, NB = 32 * NFW * WN;
+    constexpr int WA = MB, WB = 64 * ((NB + 63) / 64);
+    constexpr size_t lds = (size_t)2 * 2 * (32 * WA * 2 + 32 * WB * 2);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_stream_kernel<MFW, NFW, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int M = p.G * p.Cp;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((wgrad_stream_kernel<MFW, NFW, WN>), dim3(((M + MB - 1) / MB) * ((p.O + NB - 1) / NB), p.T * p.cpt), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_wgrad_stream(const WgradP& p, hipStream_t st) {
+    if (!wgrad_stream_ok(p.G, p.Cp, p.O) || p.kch <= 0 || (p.kch & 31) || p.cpt <= 0) return hipErrorInvalidValue;
+    if ((((uintptr_t)p.X) | ((uintptr_t)p.dY)) & 15) return hipErrorInvalidValue;
+    if (((p.step_stride | p.PS) & 3) != 0) return hipErrorInvalidValue;
+    const int M = p.G * p.Cp;
+    if (p.O <= 32) return M <= 256 ? launch_wgrad_one<1, 1, 1>(p, st) : launch_wgrad_one<2, 1, 1>(p, st);   // 256 / 512 x 32
+    if (p.O <= 64) return M <= 256 ? launch_wgrad_one<2, 1, 2>(p, st) : launch_wgrad_one<3, 1, 2>(p, st);   // 256 / 384 x 64
+    return M <= 256 ? launch_wgrad_one<2, 2, 2>(p, st) : launch_wgrad_one<3, 2, 2>(p, st);                  // 256 / 384 x 128
+}
+
+}  // namespace mcrn

@@ -1,0 +1,27 @@
+// wgrad_stream_api.h - parameter block and host entry point of the streaming weight-gradient kernel (wgrad_stream.h,
+// compiled in wgrad_stream_unit.hip).  engine.hip includes only this file.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mcrn {
+
+// slabs[z][m][o] = sum over the rows k of chunk z of  X(k, m) * dY[k][o]          (model/MegaCRN.py:26-28, backward:
+//   k = (t, r): t < T, r < R                                                         dW = X^T dY over every step and row)
+//   m = (g, c): g < G, c < Cp     X(k, m) = X[t * step_stride + g * PS + r * Cp + c]
+//   chunk z = (t, j < cpt): rows [j * kch, min(R, (j + 1) * kch)) of step t ; nslab = T * cpt
+struct WgradP {
+    const float* X;
+    long long step_stride, PS;
+    int Cp, G, T;
+    long long R;
+    const float* dY;          // [T * R][O]
+    int O;
+    float* slabs;             // [T * cpt][G * Cp][O]
+    int cpt, kch;             // kch % 32 == 0
+};
+
+// shapes the kernel takes: O <= 512, O % 4 == 0, Cp % 4 == 0, 16-byte aligned bases
+bool wgrad_stream_ok(int G, int Cp, int O);
+hipError_t launch_wgrad_stream(const WgradP& p, hipStream_t st);
+
+}  // namespace mcrn
