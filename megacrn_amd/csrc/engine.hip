@@ -680,11 +680,15 @@ static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* d
            ((step_stride | s.PS) & 3) == 0;
 }
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
-                      int O, float* slabs, hipStream_t st, int* nslab) {
+                      int O, float* slabs, hipStream_t st, int* nslab, bool* ones = nullptr) {
+    // ones != null: the caller wants the column sums of dY (bias gradient) as row G*Cp of the slabs when the streaming
+    // kernel runs (*ones = true), and computes them itself otherwise
+    if (ones) *ones = false;
     if (wgrad_streams(s, O, Xall, dYall, step_stride)) {
         WgradP q;
         q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
-        q.dY = dYall; q.O = O; q.slabs = slabs;
+        q.dY = dYall; q.O = O; q.slabs = slabs; q.ones = ones ? 1 : 0;
+        if (ones) *ones = true;
         q.cpt = NSLAB_W / T < 1 ? 1 : NSLAB_W / T;
         if (q.cpt > cdiv(s.R, 32)) q.cpt = (int)cdiv(s.R, 32);
         q.kch = (int)(cdiv(cdiv(s.R, q.cpt), 32) * 32);
@@ -774,10 +778,11 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     DsP cell_ds;
     cell_ds.nseg = 0;
-    // MCRN_DS_MERGE=1: the two AGCN calls of a cell share one adjacency-gradient launch (slab read and written once per
-    // cell).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the merged launch holds both sets
-    // and the main queue waited for it); cells now alternate between two pairs.
-    static const bool merge_ds = getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 1;
+    // The two AGCN calls of a cell share one adjacency-gradient launch (slab read and written once per cell;
+    // MCRN_DS_MERGE=0: one launch per call).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the
+    // merged launch holds both sets and the main queue waited for it); cells now alternate between two pairs
+    // (7.29 vs 7.39 ms).
+    static const bool merge_ds = !(getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0);
     DsP* cds = merge_ds ? &cell_ds : nullptr;
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
@@ -905,7 +910,7 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
         p.C[0] = o.dE_s; p.Cin[0] = o.dE_s; p.cm = plain(D); p.cn = plain(1);
         p.beta = 1.f; p.slab = (long long)N * D;
         CKI(gemm(p, which == 0, false, NSLAB_E, ROLE_MISC, st));
-        LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * D, 256)), dim3(256), 0, st, which ? o.dE2 : o.dE1, (const float*)o.dE_s, NSLAB_E,
+        LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * D, 64)), dim3(1024), 0, st, which ? o.dE2 : o.dE1, (const float*)o.dE_s, NSLAB_E,
                (long long)N * D, (long long)N * D, 0);
     }
     for (int i = 0; i < 2; ++i) {
@@ -967,9 +972,10 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
     }
     return 0;
 }
-static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st, int nslab) {
-    long long tot = (long long)2 * s.K * s.C * O;
-    LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, (long long)s.G * s.Cp * O, s.d, s.H, s.Cp, s.K, O);
+static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st, int nslab, float* dbias = nullptr) {
+    long long tot = (long long)2 * s.K * s.C * O + (dbias ? O : 0);
+    LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, (long long)(s.G * s.Cp + (dbias ? 1 : 0)) * O, s.d, s.H,
+           s.Cp, s.K, O, dbias);
     return 0;
 }
 
@@ -1041,7 +1047,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         size_t n = (size_t)sh[i]->G * sh[i]->Cp * Os[i];
         P.Wf[i] = b.take<float>(n);
         P.Wd[i] = b.take<float>(n);
-        P.dWs[i] = b.take<float>(n * NSLAB_W);
+        P.dWs[i] = b.take<float>((n + Os[i]) * NSLAB_W);   // + the column-sum row of the streaming kernel
         P.imgf[i] = b.take<uint4>(bimg_uint4(sh[i]->G * sh[i]->Cp, Os[i]));
         P.imgd[i] = b.take<uint4>(std::max(bimg_uint4(Os[i], sh[i]->G * sh[i]->Cp), wfrag_uint4(sh[i]->G * sh[i]->Cp, Os[i])));
     }
@@ -1423,7 +1429,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         q.C[0] = P.dWp_s; q.Cin[0] = P.dWp_s; q.cm = plain(Hd); q.cn = plain(1);
         q.beta = 1.f; q.slab = (long long)od * Hd;
         CKI(gemm(q, false, false, NSLAB_T, ROLE_MISC, ws_));
-        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 256)), dim3(256), 0, ws_, g->proj_w, (const float*)P.dWp_s, NSLAB_T,
+        LAUNCH(k_reduce_slabs, dim3(cdiv(od * Hd, 64)), dim3(1024), 0, ws_, g->proj_w, (const float*)P.dWp_s, NSLAB_T,
                (long long)od * Hd, (long long)od * Hd, 0);
         CKI(colsum(P.dgo, od, To * R, od, part_, g->proj_b, 0, ws_));
     }
@@ -1432,19 +1438,20 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(ds_deferred(P, sd, To, P.dPall_d, P.Ydec, P.Zdec, 0, N, st));
     }
     int ns1 = 0;
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1));
+    bool on1 = false, on2 = false, on3 = false, on4 = false;
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1));
     int ns2 = 0;
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2));
-    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1));
-    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2));
-    CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
-    CKI(colsum(P.dU_d, Hd, To * R, Hd, part_, g->dec_update_b, 0, ws_));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2));
+    CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1, on1 ? g->dec_gate_b : nullptr));
+    CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2, on2 ? g->dec_update_b : nullptr));
+    if (!on1) CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
+    if (!on2) CKI(colsum(P.dU_d, Hd, To * R, Hd, part_, g->dec_update_b, 0, ws_));
     // ---- memory head backward: dacc_d = d[h_t | value]
     CKI(memory_bwd_rows_launch(P.dacc_d, Hd, H, d_hatt, d_query, P.att_rows, p->Memory, B, N, M, D, P.dval, P.dsc, P.dq, st));
     LAUNCH(k_copy2d, dim3(cdiv(R * H, 256)), dim3(256), 0, st, P.dacc_e, (long long)H, (const float*)P.dacc_d, (long long)Hd, R, H);
     CKI(memory_bwd_gemms(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, R, H, M, D, P.att_rows, P.q_rows, P.dval, P.dsc, P.dq,
                          P.dacc_e, H, true, P.dWq_s, P.dMem_s, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_T,
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 64)), dim3(1024), 0, st, g->Wq, (const float*)P.dWq_s, NSLAB_T,
            (long long)H * D, (long long)H * D, 0);
     // ---- encoder BPTT
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
@@ -1466,13 +1473,13 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         }
     }
     int ns3 = 0;
-    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3));
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3, &on3));
     int ns4 = 0;
-    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4));
-    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st, ns3));
-    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st, ns4));
-    CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
-    CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4, &on4));
+    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st, ns3, on3 ? g->enc_gate_b : nullptr));
+    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st, ns4, on4 ? g->enc_update_b : nullptr));
+    if (!on3) CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
+    if (!on4) CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
     // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
     CKI(side_join(st));
     if (P.bf16) {
@@ -1488,7 +1495,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     } else
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
                      P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_T,
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 64)), dim3(1024), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_T,
            (long long)M * D, (long long)M * D, 0);
     if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
     if (d_neg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 1, d_neg, B, N, D);
@@ -1807,8 +1814,8 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     CKI(wunprep(dW, P.dWs, s, O, st, ns5));
     CKI(colsum(P.dY, O, s.R, O, P.part, db, 0, st));
     CKI(rows_to_bnc(dx, P.dP, s.Cp, 0, C, B, N, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
-    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 64)), dim3(1024), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 64)), dim3(1024), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
     return 0;
 }
 
@@ -1871,8 +1878,8 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CKI(colsum(P.dU, H, s.R, H, P.part, dupdate_b, 0, st));
     CKI(rows_to_bnc(dh, P.dacc, H, 0, H, B, N, st));
     if (din > 0) CKI(rows_to_bnc(dx, P.dxin, din, 0, din, B, N, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
-    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 256)), dim3(256), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 64)), dim3(1024), 0, st, ds1, (const float*)P.dS, P.nslabS, (long long)N * N, (long long)N * N, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv((long long)N * N, 64)), dim3(1024), 0, st, ds2, (const float*)(P.dS + (long long)P.nslabS * N * N), P.nslabS, (long long)N * N, (long long)N * N, 0);
     return 0;
 }
 
@@ -1909,8 +1916,8 @@ int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, cons
     CKI(memory_bwd_rows_launch(nullptr, 0, 0, dvalue, dquery, P.att, Mem, B, N, M, D, P.dval, P.dsc, P.dq, st));
     CKI(memory_bwd_gemms(P.h_rows, H, Wq, R, H, M, D, P.att, P.q_rows, P.dval, P.dsc, P.dq, P.dh_rows, H, false,
                          P.dWq_s, P.dMem_s, st));
-    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 256)), dim3(256), 0, st, dWq, (const float*)P.dWq_s, NSLAB_T, (long long)H * D, (long long)H * D, 0);
-    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dMem, (const float*)P.dMem_s, NSLAB_T, (long long)M * D, (long long)M * D, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv(H * D, 64)), dim3(1024), 0, st, dWq, (const float*)P.dWq_s, NSLAB_T, (long long)H * D, (long long)H * D, 0);
+    LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 64)), dim3(1024), 0, st, dMem, (const float*)P.dMem_s, NSLAB_T, (long long)M * D, (long long)M * D, 0);
     if (dpos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 0, dpos, B, N, D);
     if (dneg) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, dMem, (const int*)P.ind, 1, dneg, B, N, D);
     return rows_to_bnc(dh, P.dh_rows, H, 0, H, B, N, st);
@@ -1997,10 +2004,10 @@ int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, c
         CKI(gemm(p, !transA, transB != 0, nsplit, ROLE_MISC, st));
         // C = alpha*sum(slabs) (alpha already applied) + beta*C
         if (beta == 0.f) {
-            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 0);
+            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 64)), dim3(1024), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 0);
         } else {
             if (beta != 1.f) FAIL("gemm: split-K supports beta in {0,1}");
-            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 1);
+            LAUNCH(k_reduce_slabs, dim3(cdiv((long long)M * N, 64)), dim3(1024), 0, st, C, (const float*)slabs, nsplit, (long long)M * N, (long long)M * N, 1);
         }
         return 0;
     }

@@ -121,30 +121,39 @@ __global__ void k_wprep(const float* __restrict__ W, float* __restrict__ Wf, flo
 // 1024 threads = 64 consecutive outputs x 16 slab lanes (up to 256 slabs from the streaming weight-gradient kernel: one
 // thread walking them serially made this a 20 us tail); lane partials are added in a fixed order.
 __global__ __launch_bounds__(1024) void k_wunprep(float* __restrict__ dW, const float* __restrict__ slabs, int nslab,
-                                                  long long slab, int d, int H, int Cp, int K, int O) {
+                                                  long long slab, int d, int H, int Cp, int K, int O, float* __restrict__ dbias) {
     __shared__ float sh[16][64];
     const int C = d + H;
     const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + el;
     const long long tot = (long long)2 * K * C * O;
+    const long long all = tot + (dbias ? O : 0);                  // slab row G*Cp: column sums of dY = the bias gradient
     float v = 0.f;
-    if (i < tot) {
-        int o = (int)(i % O);
-        int q = (int)(i / O);
-        int cref = q % C, kg = q / C;
-        int s = kg / K, k = kg % K;
-        int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
-        int cp = cref < d ? H + cref : cref - d;
-        const float* src = slabs + ((long long)g * Cp + cp) * O + o;
+    if (i < all) {
+        long long srcoff;
+        if (i < tot) {
+            int o = (int)(i % O);
+            int q = (int)(i / O);
+            int cref = q % C, kg = q / C;
+            int s = kg / K, k = kg % K;
+            int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
+            int cp = cref < d ? H + cref : cref - d;
+            srcoff = ((long long)g * Cp + cp) * O + o;
+        } else {
+            const int G = 1 + 2 * (K - 1);
+            srcoff = (long long)G * Cp * O + (i - tot);
+        }
+        const float* src = slabs + srcoff;
         for (int z = zl; z < nslab; z += 16) v += src[z * slab];
     }
     sh[zl][el] = v;
     __syncthreads();
-    if (zl == 0 && i < tot) {
+    if (zl == 0 && i < all) {
         float t = 0.f;
 #pragma unroll
         for (int z = 0; z < 16; ++z) t += sh[z][el];
-        dW[i] = t;
+        if (i < tot) dW[i] = t;
+        else dbias[i - tot] = t;
     }
 }
 
@@ -640,14 +649,25 @@ __global__ __launch_bounds__(1024) void k_colsum_stage2(const float* __restrict_
     }
 }
 
-// out[i] = sum_z slabs[z*slab + i]
-__global__ void k_reduce_slabs(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
-                               long long slab, long long n, int accumulate) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_z slabs[z*slab + i].  1024 threads = 64 consecutive elements x 16 slab lanes (the split-K products of the
+// tiny-output gradients leave up to 256 slabs of a few thousand elements: one thread per element walked them as a
+// serial chain of 256 dependent loads, 49 us); lane partials are added in a fixed order.
+__global__ __launch_bounds__(1024) void k_reduce_slabs(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
+                                                       long long slab, long long n, int accumulate) {
+    __shared__ float sh[16][64];
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slabs[z * slab + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < n)
+        for (int z = zl; z < nslab; z += 16) s += slabs[z * slab + i];
+    sh[zl][el] = s;
+    __syncthreads();
+    if (zl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) t += sh[z][el];
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 
 // In-place first stage of a wide slab reduction: slab y (y < groups) becomes the sum of slabs y, y+groups, ...

@@ -77,17 +77,19 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
     const long long r1 = min(p.R, r0 + p.kch);
     const int nrow = r1 > r0 ? (int)(r1 - r0) : 0;
     const int nit = (nrow + 31) / 32;
-    const int nmb = (M + MB - 1) / MB;
+    const int Mt = M + (p.ones ? 1 : 0);                          // rows of the output incl. the column-sum row
+    const int nmb = (Mt + MB - 1) / MB;
     const int m0 = (blockIdx.x % nmb) * MB, n0 = (blockIdx.x / nmb) * NB;
 
     // ---- what this thread stages: row 4w + (lane >> 4) of every 32-row stage, columns 64 j + 4 (lane & 15)
     const int srow = 4 * w + (lane >> 4), c4 = lane & 15;
     unsigned offA[CGA], offB[CGB];
-    bool okA[CGA], okB[CGB];
+    bool okA[CGA], okB[CGB], oneA[CGA];
 #pragma unroll
     for (int j = 0; j < CGA; ++j) {
         const int m = m0 + 64 * j + 4 * c4;
         okA[j] = m < M;
+        oneA[j] = p.ones && m == M;                                // (M % 4 == 0: the ones row is component x of its quad)
         const int mc = okA[j] ? m : 0;
         const int g = mc / p.Cp;
         offA[j] = (unsigned)((long long)g * p.PS + (mc - g * p.Cp));
@@ -103,25 +105,36 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
     // LDS byte offset of this thread's 8 bytes inside an image: block (k / 4 = w, col / 16), row lane >> 4, 4 columns
     const int wofs = (lane >> 4) * 32 + (c4 & 3) * 8 + (c4 >> 2) * 128;
 
-    float4 va[CGA], vb[CGB];
-    auto fetch = [&](int it) {
+    // two register sets: the loads of stages it+1 AND it+2 are in flight while stage it is multiplied (one stage ahead
+    // left a CU with ~30-60 KB in flight: 2.7-4 TB/s over the chip)
+    float4 va0[CGA], vb0[CGB], va1[CGA], vb1[CGB];
+    // Loads are UNCONDITIONAL from clamped (valid) addresses and masked by a multiplication: with a select the compiler
+    // sinks each pair of loads under a divergent branch of its own, and every such block costs one full memory round
+    // trip.  (The clamped element is real data, so the 0 * x never sees a non-finite x the result would not contain.)
+    float mkA[CGA], mkB[CGB], oneAf[CGA];
+#pragma unroll
+    for (int j = 0; j < CGA; ++j) { mkA[j] = okA[j] ? 1.f : 0.f; oneAf[j] = oneA[j] ? 1.f : 0.f; }
+#pragma unroll
+    for (int j = 0; j < CGB; ++j) mkB[j] = okB[j] ? 1.f : 0.f;
+    auto fetch = [&](int it, float4 (&va)[CGA], float4 (&vb)[CGB]) {
         const int r = 32 * it + srow;
         const bool ok = r < nrow;
         const int rc = ok ? r : 0;
+        const float rk = ok ? 1.f : 0.f;
 #pragma unroll
         for (int j = 0; j < CGA; ++j) {
             const float4 v = *reinterpret_cast<const float4*>(Xt + (long long)rc * p.Cp + offA[j]);
-            const bool k = ok && okA[j];
-            va[j] = make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+            const float k = rk * mkA[j];
+            va[j] = make_float4(v.x * k + rk * oneAf[j], v.y * k, v.z * k, v.w * k);
         }
 #pragma unroll
         for (int j = 0; j < CGB; ++j) {
             const float4 v = *reinterpret_cast<const float4*>(Yt + (long long)rc * p.O + offB[j]);
-            const bool k = ok && okB[j];
-            vb[j] = make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+            const float k = rk * mkB[j];
+            vb[j] = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float4 (&va)[CGA], const float4 (&vb)[CGB]) {
         unsigned char* sA = smem_wg + buf * STAGE;               // [A hi | A lo | B hi | B lo]
         unsigned char* sB = sA + 2 * IMG_A;
 #pragma unroll
@@ -159,12 +172,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    if (nit > 0) fetch(0);
-    for (int it = 0; it < nit; ++it) {
-        const int buf = it & 1;
-        stash(buf);
-        if (it + 1 < nit) fetch(it + 1);                         // in flight during the MFMAs below
-        __syncthreads();   // stage `it` visible; every wave is done with the MFMAs of stage it-1, so buf^1 may be rewritten next
+    auto multiply = [&](int buf) {
         const unsigned char* sA = smem_wg + buf * STAGE;
         const unsigned char* sB = sA + 2 * IMG_A;
 #pragma unroll
@@ -187,10 +195,24 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
                 for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+    };
+    if (nit > 0) fetch(0, va0, vb0);
+    if (nit > 1) fetch(1, va1, vb1);
+    for (int it = 0; it < nit; it += 2) {
+        stash(0, va0, vb0);
+        if (it + 2 < nit) fetch(it + 2, va0, vb0);
+        __syncthreads();   // stage visible; every wave is done with the MFMAs of the previous stage, so the other buffer may be rewritten
+        multiply(0);
+        if (it + 1 < nit) {
+            stash(1, va1, vb1);
+            if (it + 3 < nit) fetch(it + 3, va1, vb1);
+            __syncthreads();
+            multiply(1);
+        }
     }
 
     // partial block -> slab of this chunk.  C/D layout: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
-    float* __restrict__ S = p.slabs + (long long)chunk * M * p.O;
+    float* __restrict__ S = p.slabs + (long long)chunk * Mt * p.O;
     const int l31 = lane & 31, kq = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MFW; ++i)
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int m = mb + (v & 3) + 8 * (v >> 2);
-                    if (m < M) S[(long long)m * p.O + n] = acc[i][j][v];
+                    if (m < Mt) S[(long long)m * p.O + n] = acc[i][j][v];
                 }
             }
         }
@@ -222,7 +244,7 @@ static inline hipError_t launch_wgrad_one(const WgradP& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int M = p.G * p.Cp;
+    const int M = p.G * p.Cp + (p.ones ? 1 : 0);
     (void)hipGetLastError();
     hipLaunchKernelGGL((wgrad_stream_kernel<MFW, NFW, WN>), dim3(((M + MB - 1) / MB) * ((p.O + NB - 1) / NB), p.T * p.cpt), dim3(512), lds, st, p);
     return hipGetLastError();
@@ -231,7 +253,7 @@ hipError_t launch_wgrad_stream(const WgradP& p, hipStream_t st) {
     if (!wgrad_stream_ok(p.G, p.Cp, p.O) || p.kch <= 0 || (p.kch & 31) || p.cpt <= 0) return hipErrorInvalidValue;
     if ((((uintptr_t)p.X) | ((uintptr_t)p.dY)) & 15) return hipErrorInvalidValue;
     if (((p.step_stride | p.PS) & 3) != 0) return hipErrorInvalidValue;
-    const int M = p.G * p.Cp;
+    const int M = p.G * p.Cp + (p.ones ? 1 : 0);
     if (p.O <= 32) return M <= 256 ? launch_wgrad_one<1, 1, 1>(p, st) : launch_wgrad_one<2, 1, 1>(p, st);   // 256 / 512 x 32
     if (p.O <= 64) return M <= 256 ? launch_wgrad_one<2, 1, 2>(p, st) : launch_wgrad_one<3, 1, 2>(p, st);   // 256 / 384 x 64
     return M <= 256 ? launch_wgrad_one<2, 2, 2>(p, st) : launch_wgrad_one<3, 2, 2>(p, st);                  // 256 / 384 x 128

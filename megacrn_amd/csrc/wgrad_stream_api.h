@@ -16,8 +16,10 @@ struct WgradP {
     long long R;
     const float* dY;          // [T * R][O]
     int O;
-    float* slabs;             // [T * cpt][G * Cp][O]
+    float* slabs;             // [T * cpt][G * Cp + ones][O]
     int cpt, kch;             // kch % 32 == 0
+    int ones;                 // 1: X gets a virtual all-ones column, i.e. row G*Cp of every slab = column sums of dY (the bias
+                              //    gradient, model/MegaCRN.py:28) - dY is in LDS anyway, a separate column-sum pass re-read it
 };
 
 // shapes the kernel takes: O <= 512, O % 4 == 0, Cp % 4 == 0, 16-byte aligned bases

@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
     const int T = atoi(argv[1]); const long long R = atoll(argv[2]); const int G = atoi(argv[3]), Cp = atoi(argv[4]), O = atoi(argv[5]);
     const int cpt = atoi(argv[6]), reps = argc > 7 ? atoi(argv[7]) : 10;
     const long long PS = R * Cp, ZT = (long long)G * PS;
-    const int M = G * Cp;
+    const int M0 = G * Cp, M = M0 + 1;      // + the all-ones column of X (bias gradient row)
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<float> hX((size_t)T * ZT), hY((size_t)T * R * O);
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dYd, hY.data(), hY.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dS, 0xFF, (size_t)nslab * M * O * 4));
     WgradP p; p.X = dX; p.step_stride = ZT; p.PS = PS; p.Cp = Cp; p.G = G; p.T = T; p.R = R; p.dY = dYd; p.O = O; p.slabs = dS;
-    p.cpt = cpt; p.kch = kch;
+    p.cpt = cpt; p.kch = kch; p.ones = 1;
     hipError_t e = launch_wgrad_stream(p, 0);
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 2; }
     CK(hipDeviceSynchronize());
@@ -37,15 +37,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hS.data(), dS, hS.size() * 4, hipMemcpyDeviceToHost));
     // reference on sampled output rows
     double maxerr = 0, maxref = 0;
-    std::vector<int> rows = {0, 1, Cp - 1, Cp, M / 2, M - 1};
-    for (int i = 0; i < 10; ++i) rows.push_back((int)(rng() % M));
+    std::vector<int> rows = {0, 1, Cp - 1, Cp, M0 / 2, M0 - 1, M0};
+    for (int i = 0; i < 10; ++i) rows.push_back((int)(rng() % M0));
     for (int m : rows) {
         if (m < 0 || m >= M) continue;
-        const int g = m / Cp, c = m % Cp;
+        const int g = m < M0 ? m / Cp : 0, c = m < M0 ? m % Cp : 0;
         for (int o = 0; o < O; ++o) {
             double s = 0;
             for (int t = 0; t < T; ++t)
-                for (long long r = 0; r < R; ++r) s += (double)hX[(size_t)t * ZT + (size_t)g * PS + r * Cp + c] * hY[((size_t)t * R + r) * O + o];
+                for (long long r = 0; r < R; ++r) s += (m < M0 ? (double)hX[(size_t)t * ZT + (size_t)g * PS + r * Cp + c] : 1.0) * hY[((size_t)t * R + r) * O + o];
             double got = 0;
             for (int z = 0; z < nslab; ++z) got += hS[((size_t)z * M + m) * O + o];
             maxerr = fmax(maxerr, fabs(got - s)); maxref = fmax(maxref, fabs(s));
