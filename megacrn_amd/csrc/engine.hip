@@ -303,6 +303,12 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 static inline bool use_prop_small(const Sup& u, const Shp& s) {
     return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && prop_small_ok(s.N, s.ld, (int)s.ld);
 }
+// fused two-hop kernels (cheb_k = 3): also 256 < N <= 352, where the other adjacency-stationary kernels do not reach
+static inline bool use_prop2(const Sup& u, const Shp& s) {
+    static const bool wide_off = getenv("MCRN_PROP2_WIDE") && atoi(getenv("MCRN_PROP2_WIDE")) == 0;
+    return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && s.K == 3 && prop2_ok(s.N, s.ld, (int)s.ld) &&
+           !(wide_off && s.N > 256);
+}
 
 static GemmP gp() {
     GemmP p;
@@ -440,7 +446,7 @@ static int ds_bf16(const Shp& s, const Sup& u, const uint16_t* dPb_all, const ui
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr) {
     if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st);
-    if (use_prop_small(u, s) && aligned16(Z) && s.K == 3) {   // both hops, one launch
+    if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         const double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
@@ -537,7 +543,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
-    const bool fused_bwd = small && s.K == 3 && dT != nullptr;
+    const bool fused_bwd = use_prop2(u, s) && aligned16(dP) && dT != nullptr;
     if (fused_bwd) {
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
@@ -816,7 +822,7 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     o.dLa = b.take<float>(nn); o.dLb = b.take<float>(nn); o.dLs = b.take<float>(nn);
     o.dE1 = b.take<float>(nd); o.dE2 = b.take<float>(nd);
     o.dE_s = b.take<float>(nd * NSLAB_E);
-    for (int i = 0; i < 4; ++i) o.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
+    for (int i = 0; i < 4; ++i) o.frag[i] = N <= PROP2_MAX_N ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     o.simg_n = (N + 3) & ~3;
     for (int i = 0; i < 4; ++i) o.simg[i] = N > 256 ? b.take<uint4>(bimg_uint4(N, N)) : nullptr;
 }
@@ -828,7 +834,7 @@ static int transpose(float* dst, long long ldd, const float* src, long long lds_
 }
 // fragment-ordered bf16 hi/lo images of S1, S2, S1^T, S2^T for the adjacency-stationary kernels
 static int build_frags(const float* s1, const float* s2, long long ld, int N, uint4* const* frag, hipStream_t st) {
-    if (!frag[0] || N > 256) return 0;
+    if (!frag[0] || N > PROP2_MAX_N) return 0;
     ++g_launches; CK(launch_sfrag(s1, ld, N, 0, frag[0], st));
     ++g_launches; CK(launch_sfrag(s2, ld, N, 0, frag[1], st));
     ++g_launches; CK(launch_sfrag(s1, ld, N, 1, frag[2], st));
@@ -1529,7 +1535,7 @@ static void plan_cell(int B, int N, int din, int H, int K, char* base, CellPlan&
         P.Wf[i] = b.take<float>(n); P.Wd[i] = b.take<float>(n); P.dWs[i] = b.take<float>(n * NSLAB_W);
     }
     P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
-    for (int i = 0; i < 4; ++i) P.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
+    for (int i = 0; i < 4; ++i) P.frag[i] = N <= PROP2_MAX_N ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     P.nslabS = nslab_S(N);
     P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
     P.dP = b.take<float>((size_t)s.ZT); P.dQ = b.take<float>((size_t)s.ZT);
@@ -1566,7 +1572,7 @@ static void plan_agcn(int B, int N, int C, int O, int K, char* base, AgcnPlan& P
     size_t n = (size_t)s.G * s.Cp * O;
     P.Wf = b.take<float>(n); P.Wd = b.take<float>(n); P.dWs = b.take<float>(n * NSLAB_W);
     P.St1 = b.take<float>((size_t)N * N); P.St2 = b.take<float>((size_t)N * N);
-    for (int i = 0; i < 4; ++i) P.frag[i] = N <= 256 ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
+    for (int i = 0; i < 4; ++i) P.frag[i] = N <= PROP2_MAX_N ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     P.nslabS = nslab_S(N);
     P.dS = b.take<float>((size_t)2 * P.nslabS * N * N);
     P.dP = b.take<float>((size_t)s.ZT);

@@ -149,6 +149,14 @@ template <int NF, int CT>      // CT = 32-column tiles per workgroup unit (1, 2 
 struct PropBlock {
     static constexpr int KS = 2 * NF;
     static constexpr int IMG = CT * KS * 2 * 64;     // uint4
+    // 256 < N <= 352 (NF = 9..11): a wave's S fragments for the whole K extent would be 16 NF = 176 VGPRs and the workgroup
+    // has 11 waves (3 per SIMD: 168 VGPRs each) - S is not register-stationary there: every k-step's hi and lo fragments
+    // are streamed from L2 (coalesced 2 KB per wave and k-step; the 0.5 MB image is shared by every workgroup) through a
+    // small register ring, a few k-steps ahead of the MFMAs that use them.
+    static constexpr bool WIDE = NF > 8;
+    static constexpr int NAL = WIDE ? 1 : KS;        // fragments held in registers (hi and lo alike)
+    static constexpr int RD = 3;                     // ring depth of the streamed fragments
+    static_assert(!(WIDE && CT == 1), "the wide variant is built for 2 / 3 column tiles");
     // stage 32*CT columns of a plane into the B image: thread = (4-column group, 8-k group).
     // The 8 loads are UNCONDITIONAL from clamped in-range addresses and zeroed afterwards: a load under a
     // divergent branch gets its own basic block and (measured with the in-kernel timeline) one full memory
@@ -185,19 +193,21 @@ struct PropBlock {
             }
         }
     }
-    static __device__ __forceinline__ void load_a(const uint4* __restrict__ sfw, uint4 (&ah)[KS], uint4 (&al)[KS]) {
+    static __device__ __forceinline__ void load_a(const uint4* __restrict__ sfw, uint4 (&ah)[NAL], uint4 (&al)[NAL]) {
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            ah[ks] = sfw[(ks * 2 + 0) * 64];
-            al[ks] = sfw[(ks * 2 + 1) * 64];
+            for (int ks = 0; ks < KS; ++ks) {
+                ah[ks] = sfw[(ks * 2 + 0) * 64];
+                al[ks] = sfw[(ks * 2 + 1) * 64];
+            }
         }
     }
     // acc[t] = A x img[t].  Independent accumulator chains hide the MFMA dependent-issue latency:
     // CT >= 2: the column tiles; CT == 1: the three split products, summed at the end.
     // INIT: acc already holds the addend (loaded straight into the accumulator registers: costs no extra VGPRs)
     template <bool INIT = false>
-    static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[KS], const uint4 (&al)[KS],
-                                               f32x16 (&acc)[CT], int lane) {
+    static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[NAL], const uint4 (&al)[NAL],
+                                               f32x16 (&acc)[CT], int lane, const uint4* __restrict__ sfw) {
         if constexpr (CT >= 2) {
             if constexpr (!INIT) {
 #pragma unroll
@@ -205,10 +215,22 @@ struct PropBlock {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
             }
+            uint4 rh[WIDE ? RD : 1], rl[WIDE ? RD : 1];
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int i = 0; i < RD; ++i) { rh[i] = sfw[(i * 2 + 0) * 64]; rl[i] = sfw[(i * 2 + 1) * 64]; }
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-                const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+                uint4 hi4, lo4;
+                if constexpr (WIDE) {
+                    hi4 = rh[ks % RD]; lo4 = rl[ks % RD];
+                    if (ks + RD < KS) { rh[ks % RD] = sfw[((ks + RD) * 2 + 0) * 64]; rl[ks % RD] = sfw[((ks + RD) * 2 + 1) * 64]; }
+                } else {
+                    hi4 = ah[ks]; lo4 = al[ks];
+                }
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, hi4);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, lo4);
                 bf16x8 bh[CT], bl[CT];
 #pragma unroll
                 for (int t = 0; t < CT; ++t) {
@@ -228,8 +250,8 @@ struct PropBlock {
             for (int v = 0; v < 16; ++v) { a0[v] = 0.f; a1[v] = 0.f; a2[v] = INIT ? acc[0][v] : 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-                const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[WIDE ? 0 : ks]);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, al[WIDE ? 0 : ks]);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, img[(ks * 2 + 0) * 64 + lane]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, img[(ks * 2 + 1) * 64 + lane]);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, a0, 0, 0, 0);
@@ -285,7 +307,8 @@ template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     using PB = PropBlock<NF, CT>;
     constexpr int KS = 2 * NF;
-    __shared__ uint4 img[PB::IMG];
+    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
+    uint4* const img = prop2_img;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
@@ -298,9 +321,11 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
 
     // S stays in registers while the workgroup walks its balanced range of column units: the grid is capped
     // so that all workgroups are resident at once (no second round when #units is just above #CUs)
-    uint4 ah[KS], al[KS];
+    uint4 ah[PB::NAL], al[PB::NAL];
+    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;   // (kept live only where the fragments are streamed)
     MCRN_TL(0, 0);
-    PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    PB::load_a(sfw0, ah, al);
     MCRN_TL(0, 1);
     const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
@@ -319,7 +344,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         __syncthreads();
         MCRN_TL(0, 4);
         f32x16 acc[CT];
-        PB::mma(img, ah, al, acc, lane);
+        PB::mma(img, ah, al, acc, lane, sfw);
         // X1 out (fp32) + next image
         MCRN_FRESH(ld);
 #pragma unroll
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] *= -0.5f;
-        PB::template mma<true>(img, ah, al, acc, lane);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -389,7 +414,8 @@ template <int NF, int CT>
 __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     using PB = PropBlock<NF, CT>;
     constexpr int KS = 2 * NF;
-    __shared__ uint4 img[PB::IMG];
+    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
+    uint4* const img = prop2_img;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
@@ -400,9 +426,11 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     float* __restrict__ EX = p.extra;
     const int row0 = 32 * w + 4 * kq;
     const bool rows_in = 32 * w + 32 <= p.N;
-    uint4 ah[KS], al[KS];
+    uint4 ah[PB::NAL], al[PB::NAL];
+    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;
     MCRN_TL(1, 0);
-    PB::load_a(p.Sf[s] + (long long)w * KS * 2 * 64 + lane, ah, al);
+    PB::load_a(sfw0, ah, al);
     MCRN_TL(1, 1);
     const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
@@ -439,7 +467,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         load_acc(D1, acc, ld);
         __syncthreads();
         MCRN_TL(1, 4);
-        PB::template mma<true>(img, ah, al, acc, lane);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         }
         __syncthreads();
         MCRN_TL(1, 7);
-        PB::template mma<true>(img, ah, al, acc, lane);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw);
         float* __restrict__ OUT = s == 0 ? D0 : EX;
         MCRN_FRESH(ld);
 #pragma unroll
@@ -490,16 +518,41 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
 #endif
 }
 
+#define MCRN_LAUNCH_PROP2(KERN, NF_, CT_, GRID, P)                                                        \
+    do {                                                                                                  \
+        constexpr size_t lds_ = (size_t)PropBlock<NF_, CT_>::IMG * sizeof(uint4);                         \
+        static bool set_ = false;                                                                         \
+        if (lds_ > 64 * 1024 && !set_) {                                                                  \
+            hipError_t e_ = hipFuncSetAttribute((const void*)KERN<NF_, CT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+            if (e_ != hipSuccess) return e_;                                                              \
+            set_ = true;                                                                                  \
+        }                                                                                                 \
+        hipLaunchKernelGGL((KERN<NF_, CT_>), GRID, dim3(64 * NF_), lds_, st, P);                          \
+    } while (0)
 #define MCRN_NF_SWITCH(KERN, CT_, GRID, P)                                                   \
     switch (NF) {                                                                            \
-        case 1: hipLaunchKernelGGL((KERN<1, CT_>), GRID, dim3(64), 0, st, P); break;         \
-        case 2: hipLaunchKernelGGL((KERN<2, CT_>), GRID, dim3(128), 0, st, P); break;        \
-        case 3: hipLaunchKernelGGL((KERN<3, CT_>), GRID, dim3(192), 0, st, P); break;        \
-        case 4: hipLaunchKernelGGL((KERN<4, CT_>), GRID, dim3(256), 0, st, P); break;        \
-        case 5: hipLaunchKernelGGL((KERN<5, CT_>), GRID, dim3(320), 0, st, P); break;        \
-        case 6: hipLaunchKernelGGL((KERN<6, CT_>), GRID, dim3(384), 0, st, P); break;        \
-        case 7: hipLaunchKernelGGL((KERN<7, CT_>), GRID, dim3(448), 0, st, P); break;        \
-        default: hipLaunchKernelGGL((KERN<8, CT_>), GRID, dim3(512), 0, st, P); break;       \
+        case 1: MCRN_LAUNCH_PROP2(KERN, 1, CT_, GRID, P); break;                             \
+        case 2: MCRN_LAUNCH_PROP2(KERN, 2, CT_, GRID, P); break;                             \
+        case 3: MCRN_LAUNCH_PROP2(KERN, 3, CT_, GRID, P); break;                             \
+        case 4: MCRN_LAUNCH_PROP2(KERN, 4, CT_, GRID, P); break;                             \
+        case 5: MCRN_LAUNCH_PROP2(KERN, 5, CT_, GRID, P); break;                             \
+        case 6: MCRN_LAUNCH_PROP2(KERN, 6, CT_, GRID, P); break;                             \
+        case 7: MCRN_LAUNCH_PROP2(KERN, 7, CT_, GRID, P); break;                             \
+        case 8: MCRN_LAUNCH_PROP2(KERN, 8, CT_, GRID, P); break;                             \
+        case 9: MCRN_LAUNCH_PROP2(KERN, 9, CT_, GRID, P); break;                             \
+        case 10: MCRN_LAUNCH_PROP2(KERN, 10, CT_, GRID, P); break;                           \
+        default: MCRN_LAUNCH_PROP2(KERN, 11, CT_, GRID, P); break;                           \
+    }
+#define MCRN_NF_SWITCH8(KERN, CT_, GRID, P)                                                  \
+    switch (NF) {                                                                            \
+        case 1: MCRN_LAUNCH_PROP2(KERN, 1, CT_, GRID, P); break;                             \
+        case 2: MCRN_LAUNCH_PROP2(KERN, 2, CT_, GRID, P); break;                             \
+        case 3: MCRN_LAUNCH_PROP2(KERN, 3, CT_, GRID, P); break;                             \
+        case 4: MCRN_LAUNCH_PROP2(KERN, 4, CT_, GRID, P); break;                             \
+        case 5: MCRN_LAUNCH_PROP2(KERN, 5, CT_, GRID, P); break;                             \
+        case 6: MCRN_LAUNCH_PROP2(KERN, 6, CT_, GRID, P); break;                             \
+        case 7: MCRN_LAUNCH_PROP2(KERN, 7, CT_, GRID, P); break;                             \
+        default: MCRN_LAUNCH_PROP2(KERN, 8, CT_, GRID, P); break;                            \
     }
 // column tiles per workgroup: minimise (rounds over 256 CUs) x (work per workgroup)
 static inline int pick_ct(int ncols, int ny) {
@@ -511,9 +564,9 @@ static inline int pick_ct(int ncols, int ny) {
 // workgroups each) and a launch costs `passes` unit-times, so: 64-column units when they fit in one pass; else
 // 96-column units if THOSE fit in one pass (METR-LA decoder: 136 -> 91 units, ~22 us instead of 2 x 16 us); else
 // 64-column units over just enough workgroups for the pass count (the rest of the CUs stay free for the side stream).
-static inline void prop2_shape(int ncols, int& ct, int& blocks) {
+static inline void prop2_shape(int ncols, int& ct, int& blocks, int NF) {
     const int u2 = (ncols + 63) / 64, u3 = (ncols + 95) / 96;
-    if (u2 > 128 && u3 <= 128) { ct = 3; blocks = u3; return; }
+    if (u2 > 128 && u3 <= 128 && NF <= 8) { ct = 3; blocks = u3; return; }   // (the wide variant has no registers for 3 tiles)
     const int passes = (u2 + 127) / 128;
     ct = 2; blocks = (u2 + passes - 1) / passes;
 }
@@ -521,9 +574,9 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     int ct, blocks;
-    prop2_shape(p.ncols, ct, blocks);
+    prop2_shape(p.ncols, ct, blocks, NF);
     dim3 grid(blocks, 2);
-    if (ct == 3) { MCRN_NF_SWITCH(prop2_fwd_kernel, 3, grid, p) }
+    if (ct == 3) { MCRN_NF_SWITCH8(prop2_fwd_kernel, 3, grid, p) }
     else { MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p) }
     return hipGetLastError();
 }
@@ -531,9 +584,9 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     int ct, blocks;
-    prop2_shape(p.ncols, ct, blocks);
+    prop2_shape(p.ncols, ct, blocks, NF);
     dim3 grid(blocks, 2);
-    if (ct == 3) { MCRN_NF_SWITCH(prop2_bwd_kernel, 3, grid, p) }
+    if (ct == 3) { MCRN_NF_SWITCH8(prop2_bwd_kernel, 3, grid, p) }
     else { MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p) }
     return hipGetLastError();
 }
@@ -846,6 +899,11 @@ static inline hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st) {
 
 static inline bool prop_small_ok(int N, long long ld, int ncols) {
     return N <= 256 && (ncols % 4) == 0 && (ld % 4) == 0;
+}
+// the fused two-hop kernels (cheb_k = 3) also take 256 < N <= 352 (lo fragments of S streamed, see PropBlock::WIDE)
+static const int PROP2_MAX_N = 352;
+static inline bool prop2_ok(int N, long long ld, int ncols) {
+    return N <= PROP2_MAX_N && (ncols % 4) == 0 && (ld % 4) == 0;
 }
 static inline size_t sfrag_uint4(int N) {
     const int NF = (N + 31) / 32;
