@@ -207,7 +207,7 @@ struct PropBlock {
     // INIT: acc already holds the addend (loaded straight into the accumulator registers: costs no extra VGPRs)
     template <bool INIT = false>
     static __device__ __forceinline__ void mma(const uint4* img, const uint4 (&ah)[NAL], const uint4 (&al)[NAL],
-                                               f32x16 (&acc)[CT], int lane, const uint4* __restrict__ sfw) {
+                                               f32x16 (&acc)[CT], int lane, const uint4* __restrict__ sfw, int ks0 = 0) {
         if constexpr (CT >= 2) {
             if constexpr (!INIT) {
 #pragma unroll
@@ -216,16 +216,20 @@ struct PropBlock {
                     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
             }
             uint4 rh[WIDE ? RD : 1], rl[WIDE ? RD : 1];
+            // WIDE: the k-steps are walked from a per-workgroup starting point ks0 (wrapping): all workgroups stream the
+            // SAME 0.5 MB image in lockstep, and with a common order every CU asks the same L2 channel at the same time
+            auto kof = [&](int i) { int k = i + ks0; return k >= KS ? k - KS : k; };
             if constexpr (WIDE) {
 #pragma unroll
-                for (int i = 0; i < RD; ++i) { rh[i] = sfw[(i * 2 + 0) * 64]; rl[i] = sfw[(i * 2 + 1) * 64]; }
+                for (int i = 0; i < RD; ++i) { const int k = kof(i); rh[i] = sfw[(k * 2 + 0) * 64]; rl[i] = sfw[(k * 2 + 1) * 64]; }
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+            for (int ksi = 0; ksi < KS; ++ksi) {
+                const int ks = WIDE ? kof(ksi) : ksi;
                 uint4 hi4, lo4;
                 if constexpr (WIDE) {
-                    hi4 = rh[ks % RD]; lo4 = rl[ks % RD];
-                    if (ks + RD < KS) { rh[ks % RD] = sfw[((ks + RD) * 2 + 0) * 64]; rl[ks % RD] = sfw[((ks + RD) * 2 + 1) * 64]; }
+                    hi4 = rh[ksi % RD]; lo4 = rl[ksi % RD];
+                    if (ksi + RD < KS) { const int k = kof(ksi + RD); rh[ksi % RD] = sfw[(k * 2 + 0) * 64]; rl[ksi % RD] = sfw[(k * 2 + 1) * 64]; }
                 } else {
                     hi4 = ah[ks]; lo4 = al[ks];
                 }
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     uint4 ah[PB::NAL], al[PB::NAL];
     const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
     const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;   // (kept live only where the fragments are streamed)
+    const int ks0 = PB::WIDE ? (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS) : 0;
     MCRN_TL(0, 0);
     PB::load_a(sfw0, ah, al);
     MCRN_TL(0, 1);
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         __syncthreads();
         MCRN_TL(0, 4);
         f32x16 acc[CT];
-        PB::mma(img, ah, al, acc, lane, sfw);
+        PB::mma(img, ah, al, acc, lane, sfw, ks0);
         // X1 out (fp32) + next image
         MCRN_FRESH(ld);
 #pragma unroll
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] *= -0.5f;
-        PB::template mma<true>(img, ah, al, acc, lane, sfw);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw, ks0);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     uint4 ah[PB::NAL], al[PB::NAL];
     const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
     const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;
+    const int ks0 = PB::WIDE ? (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS) : 0;
     MCRN_TL(1, 0);
     PB::load_a(sfw0, ah, al);
     MCRN_TL(1, 1);
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         load_acc(D1, acc, ld);
         __syncthreads();
         MCRN_TL(1, 4);
-        PB::template mma<true>(img, ah, al, acc, lane, sfw);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw, ks0);
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         }
         __syncthreads();
         MCRN_TL(1, 7);
-        PB::template mma<true>(img, ah, al, acc, lane, sfw);
+        PB::template mma<true>(img, ah, al, acc, lane, sfw, ks0);
         float* __restrict__ OUT = s == 0 ? D0 : EX;
         MCRN_FRESH(ld);
 #pragma unroll
