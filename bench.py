@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"], help="default: per config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roles", default="1,2,3,4,5,6", help="GEMM roles timed for gemm_roles (diagnostics)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -232,7 +233,7 @@ def main():
     # ---- roofline leg: HIP events around every launch of one GEMM role during real train steps
     roles, roof = {}, None
     if not args.no_roofline:
-        for role in range(1, 7):
+        for role in [int(r) for r in args.roles.split(",") if r]:
             check(lib.mcrn_prof_begin(role), "prof_begin")
             tr.train_step(x, ycov, y)
             ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()

@@ -215,21 +215,48 @@ struct PropBlock {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
             }
-            uint4 rh[WIDE ? RD : 1], rl[WIDE ? RD : 1];
-            // WIDE: the k-steps are walked from a per-workgroup starting point ks0 (wrapping): all workgroups stream the
-            // SAME 0.5 MB image in lockstep, and with a common order every CU asks the same L2 channel at the same time
+            // WIDE: hi and lo fragments of every k-step come from L2 through a ring of RD register pairs.  The loads are
+            // inline asm (SGPR base + the lane's 32-bit offset) with explicit vmcnt waits: written as ordinary loads the
+            // compiler - at the register limit here - sinks each one to just before its use (one exposed L2 round trip per
+            // k-step: 60 us per launch instead of ~35).  The k-steps are walked from a per-workgroup starting point ks0
+            // (wrapping): all workgroups stream the SAME 0.5 MB image in lockstep, and with a common order every CU asks
+            // the same L2 channel at the same time.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 rh[WIDE ? RD : 1], rl[WIDE ? RD : 1];
+            const unsigned char* sbase = nullptr;
+            unsigned voff = 0;
             auto kof = [&](int i) { int k = i + ks0; return k >= KS ? k - KS : k; };
+            auto issue = [&](int slot, int i) {
+                const unsigned char* b = sbase + (long long)kof(i) * 2048;       // k-step image: [hi | lo] x 64 lanes x 16 B
+                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                             : "=&v"(rh[slot]), "=&v"(rl[slot]) : "v"(voff), "s"(b));
+            };
             if constexpr (WIDE) {
+                // sfw = wave base + lane: split into the wave-uniform base and the lane's byte offset
+                const unsigned lane_b = (unsigned)(threadIdx.x & 63) * 16u;
+                sbase = reinterpret_cast<const unsigned char*>(sfw) - lane_b;
+                // (readfirstlane returns int: without the unsigned casts a low half with bit 31 set sign-extends into the high half)
+                const unsigned sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sbase);
+                const unsigned sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)sbase >> 32));
+                sbase = reinterpret_cast<const unsigned char*>(((unsigned long long)sb_hi << 32) | (unsigned long long)sb_lo);
+                voff = lane_b;
 #pragma unroll
-                for (int i = 0; i < RD; ++i) { const int k = kof(i); rh[i] = sfw[(k * 2 + 0) * 64]; rl[i] = sfw[(k * 2 + 1) * 64]; }
+                for (int i = 0; i < RD; ++i) issue(i, i);
             }
 #pragma unroll
             for (int ksi = 0; ksi < KS; ++ksi) {
                 const int ks = WIDE ? kof(ksi) : ksi;
                 uint4 hi4, lo4;
                 if constexpr (WIDE) {
-                    hi4 = rh[ksi % RD]; lo4 = rl[ksi % RD];
-                    if (ksi + RD < KS) { const int k = kof(ksi + RD); rh[ksi % RD] = sfw[(k * 2 + 0) * 64]; rl[ksi % RD] = sfw[(k * 2 + 1) * 64]; }
+                    // pair ksi has landed once at most the younger pairs (issued up to ksi + RD - 1) remain in flight
+                    constexpr int dummy = 0; (void)dummy;
+                    const int slot = ksi % RD;
+                    if (ksi + RD <= KS) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rh[slot]), "+v"(rl[slot]) : "n"(2 * (RD - 1)));
+                    else if (ksi + 2 == KS) asm volatile("s_waitcnt vmcnt(2)" : "+v"(rh[slot]), "+v"(rl[slot]));
+                    else if (ksi + 1 == KS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh[slot]), "+v"(rl[slot]));
+                    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rh[slot]), "+v"(rl[slot]) : "n"(2 * (RD - 1)));
+                    hi4 = make_uint4(rh[slot][0], rh[slot][1], rh[slot][2], rh[slot][3]);
+                    lo4 = make_uint4(rl[slot][0], rl[slot][1], rl[slot][2], rl[slot][3]);
                 } else {
                     hi4 = ah[ks]; lo4 = al[ks];
                 }
@@ -247,6 +274,9 @@ struct PropBlock {
                 for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[t], acc[t], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[t], acc[t], 0, 0, 0);
+                if constexpr (WIDE) {
+                    if (ksi + RD < KS) issue(ksi % RD, ksi + RD);    // refill the slot the MFMAs above have just read
+                }
             }
         } else {
             f32x16 a0, a1, a2;
