@@ -76,7 +76,7 @@ def pmc_traffic(config_name, dtype, N):
     d = json.load(open(path))
     if dtype == "bf16":
         keys = ("true, 1>",)                      # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
-    elif N <= 256 and dtype == "bf16x3":
+    elif N <= 352 and dtype == "bf16x3":            # fused two-hop kernels (prop_small.h: PROP2_MAX_N)
         keys = ("prop2_fwd_kernel",)
     else:
         keys = ("true, false, 1>",)               # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
@@ -99,8 +99,8 @@ def propagation_alg_bytes(cfg, B, dtype):
         else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
             out.append(2 * N * N * 4 + N * B * C * 4 + 2 * (K - 1) * N * B * C * 4)
     per_call = sum(out) / 2.0
-    # bf16x3 at N > 256 launches one hop at a time (2 launches per AGCN call): half the bytes per launch
-    hops_per_launch = 1 if (dtype != "bf16" and N > 256) else 2
+    # bf16x3 at N > 352 launches one hop at a time (2 launches per AGCN call): half the bytes per launch
+    hops_per_launch = 1 if (dtype != "bf16" and N > 352) else 2
     return per_call * hops_per_launch / 2.0
 
 
@@ -253,7 +253,7 @@ def main():
         torch.cuda.synchronize()
         check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
         kname = ("mcrn::gemm_bf16_kernel<BM,BN,..,BTR=true> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
-                 "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 256 and dtype == "bf16x3" else
+                 "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 352 and dtype == "bf16x3" else
                  "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
         launch_s = ms.value * 1e-3 / n.value
         alg_flops = af.value / n.value
