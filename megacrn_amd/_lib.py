@@ -112,6 +112,8 @@ def _load():
     lib.mcrn_get_precision.restype = i
     lib.mcrn_set_side_stream.restype = i
     lib.mcrn_set_side_stream.argtypes = [i]
+    if os.environ.get("MCRN_SIDE_STREAM") == "0":        # measurement / debugging: everything on the caller's stream
+        lib.mcrn_set_side_stream(0)
     lib.mcrn_model_autotune.restype = i
     lib.mcrn_model_autotune.argtypes = [C.POINTER(Dims), vp, sz, vp]
     lib.mcrn_autotune_entries.restype = i

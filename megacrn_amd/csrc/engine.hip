@@ -179,7 +179,7 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
 // caller has to reason about (every side launch is joined back before the call returns its last kernel).
 struct Side {
     hipStream_t st = nullptr;
-    hipEvent_t ready[4], done[4], join;          // plane sets: (update, gate) x (even, odd cell of the BPTT loop)
+    hipEvent_t ready[4], done[4], join, fork;    // plane sets: (update, gate) x (even, odd cell of the BPTT loop)
     bool ok = false, pending[4] = {false, false, false, false}, any = false;
 };
 static Side g_side;
@@ -188,12 +188,13 @@ static int side_init() {
     if (g_side.ok) return 0;
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CK(hipStreamCreateWithPriority(&g_side.st, hipStreamNonBlocking, lo));     // lowest priority: fills idle CUs
+    CK(hipStreamCreateWithPriority(&g_side.st, hipStreamNonBlocking, lo));     // lowest priority: fills idle CUs (same priority measured: no change)
     for (int i = 0; i < 4; ++i) {
         CK(hipEventCreateWithFlags(&g_side.ready[i], hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming));
     }
     CK(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
     g_side.ok = true;
     return 0;
 }
@@ -1423,8 +1424,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     float* part_ = P.part;
     if (g_use_side && !g_tuning && g_prof.role < 0) {
         CKI(side_init());
-        CK(hipEventRecord(g_side.ready[0], st));
-        CK(hipStreamWaitEvent(g_side.st, g_side.ready[0], 0));
+        CK(hipEventRecord(g_side.fork, st));         // (its own event: ready[0] belongs to the per-call launches of the loops)
+        CK(hipStreamWaitEvent(g_side.st, g_side.fork, 0));
         ws_ = g_side.st; part_ = P.part2; g_side.any = true;
     }
     {   // proj grads: dWp[j][c] = sum_{t,r} dgo[t][r][j] * h'_t[r][c]  (h'_t lives in Zdec[t+1])

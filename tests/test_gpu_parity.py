@@ -5,6 +5,7 @@ max|a-b| / max|b| per tensor.  Truth for gradients is the oracle in float64 on t
 oracle itself is pinned to the reference in tests/test_oracle_golden.py).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -642,3 +643,25 @@ def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
     # same inputs, same workspace: bit-identical
     outs2 = model(dev(x), dev(ycov), dev(y), 0)
     assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+
+
+# ------------------------------------------------------------------------------------------------
+# A/B knobs read once at library load: every alternative code path stays under the same parity tests (fresh
+# interpreter per knob).  Each line = (environment, pytest -k selection that exercises the path it switches).
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env,select", [
+    ({"MCRN_BF16_CFG": "10"}, "bf16_mode"),                          # stream-K 256 x 256 (gemm_bf16_sk_kernel)
+    ({"MCRN_BF16_CFG": "11"}, "bf16_mode"),                          # stream-K 256 x 128
+    ({"MCRN_WGRAD_STREAM": "0"}, "model_train_step or large_graph"),  # weight gradient through the tiled GEMM + column sums
+    ({"MCRN_DS_MERGE": "0"}, "model_train_step or kernel_variants"),  # one adjacency-gradient launch per AGCN call
+    ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
+])
+def test_alternative_paths_keep_parity(env, select):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        f"({select}) and not alternative_paths"], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -16,3 +16,5 @@ cd tools/kbench
 ./wgrad_test 3 900 5 24 36 85 3          # more chunks than 32-row blocks
 ./wgrad_test 12 13248 5 68 128 42 10
 ./wgrad_test 12 13248 5 68 128 10 10
+# co-residency check (see wgrad_stream.h): the launch must stay bit-identical while a 64 KB-LDS GEMM runs on another stream
+DCFG=0 CONC=30 NROT=1 ./wgrad_test 1 80000 5 28 48 256 2 | grep "CONC:"

@@ -4,11 +4,38 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <math.h>
 #include <vector>
 #include <random>
 #include "../../megacrn_amd/csrc/wgrad_stream.h"
+#include "../../megacrn_amd/csrc/gemm_bf16.h"
 using namespace mcrn;
+// POISON: fills the whole LDS of every CU with NaN bit patterns and exits (the next kernel's workgroups inherit it)
+__global__ __launch_bounds__(1024) void k_lds_poison(unsigned* sink) {
+    extern __shared__ unsigned pz[];
+    for (int i = threadIdx.x; i < 40000; i += 1024) pz[i] = 0x7FC07FC0u;
+    __syncthreads();
+    if (pz[threadIdx.x] == 1u) sink[0] = 1;
+}
+// holds 64 KB of LDS per workgroup for a while; touches none of it (HOLD=1) or fills its own region only (HOLD=2)
+__global__ __launch_bounds__(256) void k_lds_holder(int mode, int spins, unsigned* sink) {
+    __shared__ unsigned buf[16384];
+    unsigned acc = 0;
+    for (int i = 0; i < spins; ++i) {
+        if (mode == 2) buf[(threadIdx.x + 256 * i) & 16383] = i;
+        if (mode == 3) {   // hammer: full-rate 16-byte reads and writes inside the workgroup's own 64 KB
+            uint4* b4 = reinterpret_cast<uint4*>(buf);
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) { uint4 v = b4[(threadIdx.x + 37 * k + i) & 4095]; v.x += k; b4[(threadIdx.x * 3 + 11 * k + i) & 4095] = v; acc += v.y; }
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        acc += i;
+    }
+    if (mode == 2) acc += buf[threadIdx.x];
+    if (acc == 0xFFFFFFFFu) sink[0] = acc;
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
     if (argc < 7) { printf("usage: wgrad_test T R G Cp O cpt [reps]\n"); return 1; }
@@ -53,6 +80,44 @@ int main(int argc, char** argv) {
     }
     printf("T=%d R=%lld G=%d Cp=%d O=%d cpt=%d kch=%d: max|err|=%.3e max|ref|=%.3e rel %.2e %s\n", T, R, G, Cp, O, cpt, kch, maxerr, maxref,
            maxerr / maxref, maxerr / maxref < 2e-5 ? "OK" : "FAIL");
+    if (getenv("CONC")) {
+        // interference check: the same launch must give bit-identical slabs while an LDS-heavy GEMM runs on another stream
+        const int nrep = atoi(getenv("CONC"));
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        const int GM = 2048; uint16_t *gA, *gB; float* gC;
+        CK(hipMalloc(&gA, (size_t)GM * GM * 2)); CK(hipMalloc(&gB, (size_t)GM * GM * 2)); CK(hipMalloc(&gC, (size_t)GM * GM * 4));
+        CK(hipMemset(gA, 0x3c, (size_t)GM * GM * 2)); CK(hipMemset(gB, 0x3c, (size_t)GM * GM * 2));
+        Bf16GemmP g; memset(&g, 0, sizeof g);
+        g.A = gA; g.B = gB; g.am = rm_plain(GM); g.bm = rm_plain(GM); g.ldb = GM; g.nseg = 1; g.seg_len = GM; g.M = GM; g.N = GM;
+        g.C = gC; g.cm = rm_plain(GM); g.alpha = 1.f; g.xcd = 1;
+        std::vector<float> h2(hS.size());
+        int bad = 0;
+        for (int it = 0; it < nrep; ++it) {
+            CK(hipMemsetAsync(dS, 0xFF, hS.size() * 4, s1));
+            if (getenv("POISON")) { static bool a_ = false; if (!a_) { hipFuncSetAttribute((const void*)k_lds_poison, hipFuncAttributeMaxDynamicSharedMemorySize, 160000); a_ = true; } hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(1024), 160000, s1, (unsigned*)gC); }
+            else if (getenv("HOLD")) hipLaunchKernelGGL(k_lds_holder, dim3(getenv("HOLDN") ? atoi(getenv("HOLDN")) : 200), dim3(256), 0, s2, atoi(getenv("HOLD")), 400, (unsigned*)gC);
+            else if (getenv("DCFG")) { for (int k = 0; k < 4; ++k) launch_gemm_bf16(g, getenv("DBTR") != nullptr, atoi(getenv("DCFG")), 1, 0, s2); }
+            else for (int k = 0; k < 4; ++k) launch_gemm_bf16(g, (it & 1) != 0, it % 10, 1, 0, s2);
+            launch_wgrad_stream(p, s1);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h2.data(), dS, h2.size() * 4, hipMemcpyDeviceToHost));
+            size_t nd = 0; double md = 0;
+            for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != hS[i]) { ++nd; md = fmax(md, fabs((double)h2[i] - hS[i])); }
+            if (nd) {
+                ++bad; printf("   conc iter %d: %zu of %zu slab values differ (max %.3e)\n", it, nd, h2.size(), md);
+                if (bad <= 2) {
+                    std::vector<int> perz(nslab, 0), perm(M, 0), pero(O, 0);
+                    for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != hS[i]) { perz[i / ((size_t)M * O)]++; perm[(i / O) % M]++; pero[i % O]++; }
+                    printf("      chunks:"); for (int z = 0; z < nslab; ++z) if (perz[z]) printf(" %d(%d)", z, perz[z]); printf("\n      rows m:");
+                    for (int m = 0; m < M; ++m) if (perm[m]) printf(" %d", m); printf("\n      cols o:");
+                    for (int o = 0; o < O; ++o) if (pero[o]) printf(" %d", o); printf("\n");
+                    size_t shown = 0;
+                    for (size_t i = 0; i < h2.size() && shown < 6; ++i) if (h2[i] != hS[i]) { printf("      [%zu] solo %.6f conc %.6f\n", i, hS[i], h2[i]); ++shown; }
+                }
+            }
+        }
+        printf("   CONC: %d of %d runs differ from the solo run\n", bad, nrep);
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // rotate over NROT copies of the operands (env, default 6): every launch streams data that is in no cache, as in a train step
     const int nrot = getenv("NROT") ? atoi(getenv("NROT")) : 6;
