@@ -53,6 +53,9 @@ __device__ __forceinline__ bf16x8_t frag(const unsigned char* img, int off, int 
 }
 }  // namespace wgs
 
+#ifdef MCRN_WGS_DEBUG
+__device__ unsigned g_wgs_dbg[4096];   // per workgroup: HW_REG_LDS_ALLOC of wave 0 (harness diagnostics)
+#endif
 // 8 waves = WM x WN; a wave owns MFW x NFW fragments of 32 x 32: output block (32 MFW WM) x (32 NFW WN)
 template <int MFW, int NFW, int WN>
 __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
@@ -70,6 +73,9 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / WN, wn = w % WN;
     const int M = p.G * p.Cp;
+#ifdef MCRN_WGS_DEBUG
+    if (tid == 0 && blockIdx.x == 0) { unsigned r; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(r)); g_wgs_dbg[blockIdx.y & 4095] = r; }
+#endif
     // grid: y = row chunk, x = (row block, column block) of the output - the workgroups that re-read a chunk (outputs
     // larger than one block: M > 384 or O > 128) are dispatched together and meet in the memory-side cache
     const int chunk = blockIdx.y;
@@ -165,36 +171,51 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
     for (int j = 0; j < NFW; ++j) boff[j] = ((2 * (gq >> 1)) * (WB / 16) + (wn * NFW + j) * 2 + (gq & 1)) * 128 + lofs;
 
-    f32x16_t acc[MFW][NFW];
+    // NACC accumulator sets: with one or two fragments per wave the three products of a k-step would be a chain of
+    // back-to-back DEPENDENT MFMAs on the same registers; each product gets its own accumulator there (summed once at the
+    // end), so that consecutive MFMAs of a wave never depend on each other.
+#ifdef MCRN_WGS_NACC1
+    constexpr int NACC = 1;                                      // (harness experiment: the unprotected chains)
+#else
+    constexpr int NACC = (MFW * NFW <= 2) ? 3 : 1;
+#endif
+    f32x16_t acc[NACC][MFW][NFW];
 #pragma unroll
-    for (int i = 0; i < MFW; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int j = 0; j < NFW; ++j)
+        for (int i = 0; i < MFW; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+            for (int j = 0; j < NFW; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[a][i][j][v] = 0.f;
 
     auto multiply = [&](int buf) {
         const unsigned char* sA = smem_wg + buf * STAGE;
         const unsigned char* sB = sA + 2 * IMG_A;
+        // all fragments of the stage (both k-steps) first, then the MFMAs: no fragment register is reloaded while an MFMA
+        // that reads it may still be waiting for the matrix pipe (see the note at launch_wgrad_one)
+        bf16x8_t ah[2][MFW], al[2][MFW], bh[2][NFW], bl[2][NFW];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t ah[MFW], al[MFW], bh[NFW], bl[NFW];
 #pragma unroll
-            for (int i = 0; i < MFW; ++i) { ah[i] = frag<WA>(sA, aoff[i], ks); al[i] = frag<WA>(sA + IMG_A, aoff[i], ks); }
+            for (int i = 0; i < MFW; ++i) { ah[ks][i] = frag<WA>(sA, aoff[i], ks); al[ks][i] = frag<WA>(sA + IMG_A, aoff[i], ks); }
 #pragma unroll
-            for (int j = 0; j < NFW; ++j) { bh[j] = frag<WB>(sB, boff[j], ks); bl[j] = frag<WB>(sB + IMG_B, boff[j], ks); }
+            for (int j = 0; j < NFW; ++j) { bh[ks][j] = frag<WB>(sB, boff[j], ks); bl[ks][j] = frag<WB>(sB + IMG_B, boff[j], ks); }
+        }
 #pragma unroll
-            for (int i = 0; i < MFW; ++i)
-#pragma unroll
-                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < MFW; ++i)
 #pragma unroll
-                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NFW; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[0][i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < MFW; ++i)
 #pragma unroll
-                for (int j = 0; j < NFW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NFW; ++j) acc[NACC == 3 ? 1 : 0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[NACC == 3 ? 1 : 0][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MFW; ++i)
+#pragma unroll
+                for (int j = 0; j < NFW; ++j) acc[NACC == 3 ? 2 : 0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[NACC == 3 ? 2 : 0][i][j], 0, 0, 0);
         }
     };
     if (nit > 0) fetch(0, va0, vb0);
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int m = mb + (v & 3) + 8 * (v >> 2);
-                    if (m < Mt) S[(long long)m * p.O + n] = acc[i][j][v];
+                    if (m < Mt) S[(long long)m * p.O + n] = NACC == 3 ? (acc[0][i][j][v] + acc[1][i][j][v]) + acc[2][i][j][v] : acc[0][i][j][v];
                 }
             }
         }
@@ -238,13 +259,20 @@ static inline hipError_t launch_wgrad_one(const WgradP& p, hipStream_t st) {
     constexpr int WM = 8 / WN, MB = 32 * MFW * WM, NB = 32 * NFW * WN;
     constexpr int WA = MB, WB = 64 * ((NB + 63) / 64);
     constexpr size_t lds_need = (size_t)2 * 2 * (32 * WA * 2 + 32 * WB * 2);
-    // The kernel asks for the WHOLE LDS of a CU (160 KB), not just what it uses.  Measured (tools/kbench/wgrad_test with
-    // CONC=..: this kernel on one stream, an LDS + MFMA GEMM of 64 KB per workgroup on another): whenever a workgroup of
-    // the 80 KB variants shares a CU with such a GEMM workgroup, some of its A fragments come back wrong (lanes = 1 mod 4
-    // of the transposing reads of waves 0,1,4,5; bitwise reproducible alone, with a passive or a self-contained LDS-hammering
-    // neighbour, and with exclusive LDS).  In the model it showed as a 1e-3 error of the decoder gate weight gradient
-    // when the helper stream's weight gradient overlapped the memory-head GEMMs.  The mechanism is not understood
-    // (DESIGN.md section 8); exclusivity removes every co-resident LDS user.  MCRN_WGS_SHARED=1 restores the old request.
+    // The kernel asks for the WHOLE LDS of a CU (160 KB), not just what it uses, so that no other LDS-using workgroup
+    // (= no other MFMA kernel of this library) can share its CU.  Measured with tools/kbench/wgrad_test (CONC=..: this
+    // kernel on one stream, a neighbour on another; the slabs must stay bit-identical to the solo run):
+    //   * neighbour = MFMA-dense waves on the same SIMDs (a GEMM with 64 KB of LDS, or a register-only MFMA loop): the
+    //     variants with < 256 VGPRs (room for foreign waves on their SIMDs) return wrong values in accumulator registers
+    //     1, 5, 9, 13 of some fragments, in every run;
+    //   * neighbour = passive LDS holder, LDS read/write hammer, LDS-fed (slow) MFMA, or none: bit-identical, thousands of
+    //     launches; the bf16 GEMM kernels of gemm_bf16.h under the same MFMA neighbour: bit-identical;
+    //   * dependent-MFMA distance, full lgkmcnt waits after the transposing reads, integer instead of asm bf16 rounding,
+    //     fragment loads hoisted in front of the MFMAs: no effect.
+    // In the model it showed as a 1e-3 error of the decoder gate weight gradient when the helper stream's weight gradient
+    // overlapped the memory-head GEMMs (per-call adjacency-gradient mode; found by tests/test_gpu_parity.py::
+    // test_alternative_paths_keep_parity).  The mechanism is NOT understood; exclusivity removes every
+    // co-resident MFMA user this library has.  MCRN_WGS_SHARED=1 restores the minimal request (harness experiments).
     static const bool lds_shared = getenv("MCRN_WGS_SHARED") != nullptr;
     const size_t lds = lds_shared ? lds_need : (size_t)160 * 1024;
     static_assert(lds_need <= 160 * 1024, "LDS");

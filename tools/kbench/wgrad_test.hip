@@ -8,6 +8,7 @@
 #include <math.h>
 #include <vector>
 #include <random>
+#define MCRN_WGS_DEBUG 1
 #include "../../megacrn_amd/csrc/wgrad_stream.h"
 #include "../../megacrn_amd/csrc/gemm_bf16.h"
 using namespace mcrn;
@@ -17,6 +18,17 @@ __global__ __launch_bounds__(1024) void k_lds_poison(unsigned* sink) {
     for (int i = threadIdx.x; i < 40000; i += 1024) pz[i] = 0x7FC07FC0u;
     __syncthreads();
     if (pz[threadIdx.x] == 1u) sink[0] = 1;
+}
+// MFMA-only neighbour without LDS: co-resident with every variant of the kernel under test
+__global__ __launch_bounds__(256) void k_mfma_neighbour(int spins, unsigned* sink) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v c = {0};
+    uint4 u = make_uint4(0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    for (int i = 0; i < spins; ++i)
+#pragma unroll 4
+        for (int k = 0; k < 64; ++k) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, u), __builtin_bit_cast(b8, u), c, 0, 0, 0);
+    if ((unsigned)c[0] == 0xFFFFFFFFu) sink[0] = 1;
 }
 // holds 64 KB of LDS per workgroup for a while; touches none of it (HOLD=1) or fills its own region only (HOLD=2)
 __global__ __launch_bounds__(256) void k_lds_holder(int mode, int spins, unsigned* sink) {
@@ -28,6 +40,20 @@ __global__ __launch_bounds__(256) void k_lds_holder(int mode, int spins, unsigne
             uint4* b4 = reinterpret_cast<uint4*>(buf);
 #pragma unroll 8
             for (int k = 0; k < 64; ++k) { uint4 v = b4[(threadIdx.x + 37 * k + i) & 4095]; v.x += k; b4[(threadIdx.x * 3 + 11 * k + i) & 4095] = v; acc += v.y; }
+            continue;
+        }
+        if (mode == 4 || mode == 5) {   // MFMA (+ 16-byte LDS reads feeding it, mode 5)
+            typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            uint4* b4 = reinterpret_cast<uint4*>(buf);
+            f16v c = {0};
+            uint4 u = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+#pragma unroll 4
+            for (int k = 0; k < 64; ++k) {
+                if (mode == 5) u = b4[(threadIdx.x + 64 * k + i) & 4095];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, u), __builtin_bit_cast(b8, u), c, 0, 0, 0);
+            }
+            acc += (unsigned)c[0];
             continue;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -90,11 +116,32 @@ int main(int argc, char** argv) {
         Bf16GemmP g; memset(&g, 0, sizeof g);
         g.A = gA; g.B = gB; g.am = rm_plain(GM); g.bm = rm_plain(GM); g.ldb = GM; g.nseg = 1; g.seg_len = GM; g.M = GM; g.N = GM;
         g.C = gC; g.cm = rm_plain(GM); g.alpha = 1.f; g.xcd = 1;
+        if (getenv("VICTIM")) {   // the bf16 GEMM as the kernel under test: configuration VICTIM, 1024^3, against the MFMA neighbour
+            const int vc = atoi(getenv("VICTIM")), VM = 1024;
+            Bf16GemmP v = g; v.M = VM; v.N = VM; v.seg_len = VM;
+            std::vector<float> c0((size_t)VM * GM), c1((size_t)VM * GM);
+            CK(hipMemsetAsync(gC, 0, (size_t)GM * GM * 4, s1));
+            std::vector<uint16_t> ra((size_t)GM * GM); for (auto& x : ra) x = (uint16_t)(0x3c00 + (rng() & 0x1ff));
+            CK(hipMemcpy(gA, ra.data(), ra.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(gB, ra.data(), ra.size() * 2, hipMemcpyHostToDevice));
+            launch_gemm_bf16(v, getenv("DBTR") != nullptr, vc, 1, 0, s1); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(c0.data(), gC, c0.size() * 4, hipMemcpyDeviceToHost));
+            int badv = 0;
+            for (int it = 0; it < nrep; ++it) {
+                hipLaunchKernelGGL(k_mfma_neighbour, dim3(1024), dim3(256), 0, s2, 400, (unsigned*)gB);
+                launch_gemm_bf16(v, getenv("DBTR") != nullptr, vc, 1, 0, s1); CK(hipDeviceSynchronize());
+                CK(hipMemcpy(c1.data(), gC, c1.size() * 4, hipMemcpyDeviceToHost));
+                size_t nd = 0; for (size_t i = 0; i < c0.size(); ++i) nd += c0[i] != c1[i];
+                if (nd) ++badv;
+            }
+            printf("   VICTIM gemm_bf16 cfg %d: %d of %d runs differ from the solo run\n", vc, badv, nrep);
+            return 0;
+        }
         std::vector<float> h2(hS.size());
         int bad = 0;
         for (int it = 0; it < nrep; ++it) {
             CK(hipMemsetAsync(dS, 0xFF, hS.size() * 4, s1));
             if (getenv("POISON")) { static bool a_ = false; if (!a_) { hipFuncSetAttribute((const void*)k_lds_poison, hipFuncAttributeMaxDynamicSharedMemorySize, 160000); a_ = true; } hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(1024), 160000, s1, (unsigned*)gC); }
+            else if (getenv("MFMAN")) hipLaunchKernelGGL(k_mfma_neighbour, dim3(atoi(getenv("MFMAN"))), dim3(256), 0, s2, 400, (unsigned*)gC);
             else if (getenv("HOLD")) hipLaunchKernelGGL(k_lds_holder, dim3(getenv("HOLDN") ? atoi(getenv("HOLDN")) : 200), dim3(256), 0, s2, atoi(getenv("HOLD")), 400, (unsigned*)gC);
             else if (getenv("DCFG")) { for (int k = 0; k < 4; ++k) launch_gemm_bf16(g, getenv("DBTR") != nullptr, atoi(getenv("DCFG")), 1, 0, s2); }
             else for (int k = 0; k < 4; ++k) launch_gemm_bf16(g, (it & 1) != 0, it % 10, 1, 0, s2);
@@ -106,8 +153,11 @@ int main(int argc, char** argv) {
             if (nd) {
                 ++bad; printf("   conc iter %d: %zu of %zu slab values differ (max %.3e)\n", it, nd, h2.size(), md);
                 if (bad <= 2) {
+                    unsigned hreg[256]; CK(hipMemcpyFromSymbol(hreg, HIP_SYMBOL(mcrn::g_wgs_dbg), sizeof hreg));
+                    printf("      LDS_ALLOC of the differing chunks:"); 
                     std::vector<int> perz(nslab, 0), perm(M, 0), pero(O, 0);
                     for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != hS[i]) { perz[i / ((size_t)M * O)]++; perm[(i / O) % M]++; pero[i % O]++; }
+                    { std::vector<int> pz(nslab, 0); for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != hS[i]) pz[i / ((size_t)M * O)]++; for (int z = 0; z < nslab && z < 256; ++z) if (pz[z]) printf(" %d:%08x", z, hreg[z]); printf("\n      LDS_ALLOC histogram of all chunks:"); std::vector<unsigned> seen; for (int z = 0; z < nslab && z < 256; ++z) { bool f = false; for (unsigned u : seen) f |= u == hreg[z]; if (!f) { seen.push_back(hreg[z]); int c = 0, cb = 0; for (int y = 0; y < nslab && y < 256; ++y) if (hreg[y] == hreg[z]) { ++c; cb += pz[y] != 0; } printf(" %08x x%d(bad %d)", hreg[z], c, cb); } } printf("\n"); }
                     printf("      chunks:"); for (int z = 0; z < nslab; ++z) if (perz[z]) printf(" %d(%d)", z, perz[z]); printf("\n      rows m:");
                     for (int m = 0; m < M; ++m) if (perm[m]) printf(" %d", m); printf("\n      cols o:");
                     for (int o = 0; o < O; ++o) if (pero[o]) printf(" %d", o); printf("\n");
