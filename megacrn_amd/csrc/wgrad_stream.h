@@ -189,6 +189,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[a][i][j][v] = 0.f;
 
+    unsigned probe[4] = {0u, 0u, 0u, 0u};
+    (void)probe;
     auto multiply = [&](int buf) {
         const unsigned char* sA = smem_wg + buf * STAGE;
         const unsigned char* sB = sA + 2 * IMG_A;
@@ -202,6 +204,16 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
             for (int j = 0; j < NFW; ++j) { bh[ks][j] = frag<WB>(sB, boff[j], ks); bl[ks][j] = frag<WB>(sB + IMG_B, boff[j], ks); }
         }
+#ifdef MCRN_WGS_PROBE   // harness diagnostics: no MFMA, an integer checksum of every fragment the MFMAs would read
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MFW; ++i) { const uint4 a = __builtin_bit_cast(uint4, ah[ks][i]), b = __builtin_bit_cast(uint4, al[ks][i]); probe[0] += a.x ^ (b.x * 3u); probe[1] += a.y ^ (b.y * 5u); probe[2] += a.z ^ (b.z * 7u); probe[3] += a.w ^ (b.w * 11u); }
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) { const uint4 a = __builtin_bit_cast(uint4, bh[ks][j]), b = __builtin_bit_cast(uint4, bl[ks][j]); probe[0] += 13u * a.x ^ b.x; probe[1] += 17u * a.y ^ b.y; probe[2] += 19u * a.z ^ b.z; probe[3] += 23u * a.w ^ b.w; }
+        }
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -235,6 +247,9 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 
     // partial block -> slab of this chunk.  C/D layout: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
     float* __restrict__ S = p.slabs + (long long)chunk * Mt * p.O;
+#ifdef MCRN_WGS_PROBE
+    if (Mt * p.O >= 2048 && blockIdx.x == 0) { for (int q = 0; q < 4; ++q) S[q * 512 + tid] = __uint_as_float(probe[q] & 0x3FFFFFFFu); return; }
+#endif
     const int l31 = lane & 31, kq = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MFW; ++i)

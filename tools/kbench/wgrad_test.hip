@@ -149,7 +149,7 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(h2.data(), dS, h2.size() * 4, hipMemcpyDeviceToHost));
             size_t nd = 0; double md = 0;
-            for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != hS[i]) { ++nd; md = fmax(md, fabs((double)h2[i] - hS[i])); }
+            for (size_t i = 0; i < h2.size(); ++i) if (memcmp(&h2[i], &hS[i], 4) != 0) { ++nd; md = fmax(md, fabs((double)h2[i] - hS[i])); }
             if (nd) {
                 ++bad; printf("   conc iter %d: %zu of %zu slab values differ (max %.3e)\n", it, nd, h2.size(), md);
                 if (bad <= 2) {
