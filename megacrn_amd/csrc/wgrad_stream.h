@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
         for (int j = 0; j < CGA; ++j) {
             const float4 v = *reinterpret_cast<const float4*>(Xt + (long long)rc * p.Cp + offA[j]);
             const float k = rk * mkA[j];
-            va[j] = make_float4(v.x * k + rk * oneAf[j], v.y * k, v.z * k, v.w * k);
+            const float x_ = v.x * k;
+            va[j] = make_float4(oneA[j] ? rk : x_, v.y * k, v.z * k, v.w * k);   // (a select: the fused form became v_pk_fma_f32, see launch_wgrad_one)
         }
 #pragma unroll
         for (int j = 0; j < CGB; ++j) {
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
             vb[j] = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
         }
     };
+    unsigned probe[4] = {0u, 0u, 0u, 0u};
+    (void)probe;
     auto stash = [&](int buf, const float4 (&va)[CGA], const float4 (&vb)[CGB]) {
         unsigned char* sA = smem_wg + buf * STAGE;               // [A hi | A lo | B hi | B lo]
         unsigned char* sB = sA + 2 * IMG_A;
@@ -148,6 +151,9 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
         for (int j = 0; j < CGA; ++j) {
             uint2 h, l;
             split4(va[j], h, l);
+#if defined(MCRN_WGS_PROBE) && MCRN_WGS_PROBE == 2
+            probe[0] += h.x ^ (l.x * 3u); probe[1] += h.y ^ (l.y * 5u); probe[2] += __float_as_uint(va[j].x) ^ __float_as_uint(va[j].w); probe[3] += __float_as_uint(va[j].y) * 7u ^ __float_as_uint(va[j].z);
+#endif
             const int o = (w * (WA / 16) + 4 * j) * 128 + wofs;
             *reinterpret_cast<uint2*>(sA + o) = h;
             *reinterpret_cast<uint2*>(sA + IMG_A + o) = l;
@@ -189,8 +195,6 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[a][i][j][v] = 0.f;
 
-    unsigned probe[4] = {0u, 0u, 0u, 0u};
-    (void)probe;
     auto multiply = [&](int buf) {
         const unsigned char* sA = smem_wg + buf * STAGE;
         const unsigned char* sB = sA + 2 * IMG_A;
@@ -204,6 +208,9 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 #pragma unroll
             for (int j = 0; j < NFW; ++j) { bh[ks][j] = frag<WB>(sB, boff[j], ks); bl[ks][j] = frag<WB>(sB + IMG_B, boff[j], ks); }
         }
+#if defined(MCRN_WGS_PROBE) && MCRN_WGS_PROBE == 2
+        return;   // (probe 2: checksum of the VALUES WRITTEN to LDS, taken in stash)
+#endif
 #ifdef MCRN_WGS_PROBE   // harness diagnostics: no MFMA, an integer checksum of every fragment the MFMAs would read
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -274,22 +281,17 @@ static inline hipError_t launch_wgrad_one(const WgradP& p, hipStream_t st) {
     constexpr int WM = 8 / WN, MB = 32 * MFW * WM, NB = 32 * NFW * WN;
     constexpr int WA = MB, WB = 64 * ((NB + 63) / 64);
     constexpr size_t lds_need = (size_t)2 * 2 * (32 * WA * 2 + 32 * WB * 2);
-    // The kernel asks for the WHOLE LDS of a CU (160 KB), not just what it uses, so that no other LDS-using workgroup
-    // (= no other MFMA kernel of this library) can share its CU.  Measured with tools/kbench/wgrad_test (CONC=..: this
-    // kernel on one stream, a neighbour on another; the slabs must stay bit-identical to the solo run):
-    //   * neighbour = MFMA-dense waves on the same SIMDs (a GEMM with 64 KB of LDS, or a register-only MFMA loop): the
-    //     variants with < 256 VGPRs (room for foreign waves on their SIMDs) return wrong values in accumulator registers
-    //     1, 5, 9, 13 of some fragments, in every run;
-    //   * neighbour = passive LDS holder, LDS read/write hammer, LDS-fed (slow) MFMA, or none: bit-identical, thousands of
-    //     launches; the bf16 GEMM kernels of gemm_bf16.h under the same MFMA neighbour: bit-identical;
-    //   * dependent-MFMA distance, full lgkmcnt waits after the transposing reads, integer instead of asm bf16 rounding,
-    //     fragment loads hoisted in front of the MFMAs: no effect.
-    // In the model it showed as a 1e-3 error of the decoder gate weight gradient when the helper stream's weight gradient
-    // overlapped the memory-head GEMMs (per-call adjacency-gradient mode; found by tests/test_gpu_parity.py::
-    // test_alternative_paths_keep_parity).  The mechanism is NOT understood; exclusivity removes every
-    // co-resident MFMA user this library has.  MCRN_WGS_SHARED=1 restores the minimal request (harness experiments).
-    static const bool lds_shared = getenv("MCRN_WGS_SHARED") != nullptr;
-    const size_t lds = lds_shared ? lds_need : (size_t)160 * 1024;
+    // History of a wrong turn worth keeping: this kernel returned 1e-3-wrong weight gradients whenever
+    // another kernel's MFMA-dense waves shared its SIMDs (found by tests/test_gpu_parity.py::
+    // test_alternative_paths_keep_parity, reproduced with tools/kbench/wgrad_test CONC / MFMAN).  Not LDS, not the
+    // transposing reads, not the MFMA chains: the mask multiplications of fetch() had been SLP-vectorised into
+    // v_pk_mul_f32 / v_pk_fma_f32, and the HIGH half of a packed-fp32 VALU instruction comes back wrong under a foreign
+    // MFMA stream on the same SIMD (the probe builds -DMCRN_WGS_PROBE=1/2 showed the values wrong before they reach LDS).
+    // The whole library is now built with -fno-slp-vectorize -fno-vectorize (csrc/Makefile; tests/test_host_cpu.py checks
+    // the shipped code objects for packed-fp32 instructions).  MCRN_WGS_EXCL=1 asks for the whole LDS of a CU (nothing
+    // co-resident), the stop-gap used while the cause was unknown.
+    static const bool lds_excl = getenv("MCRN_WGS_EXCL") != nullptr;
+    const size_t lds = lds_excl ? (size_t)160 * 1024 : lds_need;
     static_assert(lds_need <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {

@@ -1,5 +1,5 @@
 // Stand-alone correctness + timing harness for megacrn_amd/csrc/wgrad_stream.h (no torch).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o wgrad_test wgrad_test.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-vectorize -o wgrad_test wgrad_test.hip    (the library's flags)
 //   ./wgrad_test T R G Cp O cpt reps
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -152,6 +152,7 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < h2.size(); ++i) if (memcmp(&h2[i], &hS[i], 4) != 0) { ++nd; md = fmax(md, fabs((double)h2[i] - hS[i])); }
             if (nd) {
                 ++bad; printf("   conc iter %d: %zu of %zu slab values differ (max %.3e)\n", it, nd, h2.size(), md);
+                { size_t qh[4] = {0, 0, 0, 0}, other = 0; const size_t slab = (size_t)M * O; for (size_t i = 0; i < h2.size(); ++i) if (memcmp(&h2[i], &hS[i], 4) != 0) { const size_t w = i % slab; if (w < 2048) qh[w / 512]++; else other++; } printf("      probe words differing: q0 %zu q1 %zu q2 %zu q3 %zu other %zu\n", qh[0], qh[1], qh[2], qh[3], other); }
                 if (bad <= 2) {
                     unsigned hreg[256]; CK(hipMemcpyFromSymbol(hreg, HIP_SYMBOL(mcrn::g_wgs_dbg), sizeof hreg));
                     printf("      LDS_ALLOC of the differing chunks:"); 
