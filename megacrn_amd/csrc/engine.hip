@@ -1301,18 +1301,43 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const int Ti = d->T_in, To = d->T_out;
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
+    // The step opens with ~40 tiny, mutually independent preparation launches (supports, weight images, input packing:
+    // ~0.45 ms of the 6.7 ms METR-LA step, each 5 us of work behind 7 us of launch gap).  Everything that depends on
+    // the WEIGHTS and the decoder's inputs only goes to the helper stream and is joined before the first cell.
+    hipStream_t ps = st;
+    const bool forked = g_use_side && !g_tuning && g_prof.role < 0;
+    if (forked) {
+        CKI(side_init());
+        CK(hipEventRecord(g_side.fork, st));
+        CK(hipStreamWaitEvent(g_side.st, g_side.fork, 0));
+        ps = g_side.st;
+    }
+    const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
+    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
+    for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], ps, P.imgf[i], P.imgd[i]));
+    // decoder input columns (:181-183): covariates, zero pad columns, go symbol = 0; the state columns of Zdec[0] are
+    // written by the memory head after the encoder
+    if (yd > 0) {
+        CKI(fill_cols(P.Zdec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, ps));
+        CKI(fill_cols(P.Ydec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, ps));
+    }
+    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
+    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
+    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));   // go = 0 (:182)
+    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));
     CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
     Sup u = model_sup(P, N);
     if (P.bf16) CKI(build_stacks(P, u, N, d->cheb_k, st));
-    const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
-    const int Os[4] = {2 * H, H, 2 * Hd, Hd};
-    for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], st, P.imgf[i], P.imgd[i]));
     // ---- encoder (MegaCRN.py:65-83): inputs for all t packed once
     CKI(fill_cols(P.Zenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
     CKI(fill_cols(P.Yenc, se.ZT, se.Cp, H, din, x, (long long)Ti * N * din, (long long)N * din, din, B, N, Ti, st));
     CKI(zero_cols(P.Zenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
     CKI(zero_cols(P.Yenc, se.ZT, se.Cp, se.C, se.Cp, R, Ti, st));
     CKI(zero_cols(P.Zenc, se.ZT, se.Cp, 0, H, R, 1, st));   // init_hidden = 0 (:50-51)
+    if (forked) {
+        CK(hipEventRecord(g_side.join, g_side.st));
+        CK(hipStreamWaitEvent(st, g_side.join, 0));
+    }
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     for (int t = 0; t < Ti; ++t)
         CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
@@ -1321,15 +1346,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
                           P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
-    // ---- decoder (:181-192)
-    if (yd > 0) {
-        CKI(fill_cols(P.Zdec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, st));
-        CKI(fill_cols(P.Ydec, sd.ZT, sd.Cp, Hd + od, yd, ycov, (long long)To * N * yd, (long long)N * yd, yd, B, N, To, st));
-    }
-    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, st));
-    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, st));
-    CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));   // go = 0 (:182)
-    CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, st));
+    // ---- decoder (:181-192): its input columns were packed at the top of the step
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
