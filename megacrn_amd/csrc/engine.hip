@@ -1961,8 +1961,7 @@ int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, flo
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     LAUNCH(k_clip_adam, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, max_norm,
-           grad_scale, (const float*)(scratch + 1000));
-    if (total_norm_out) CK(hipMemcpyAsync(total_norm_out, scratch + 1000, sizeof(float), hipMemcpyDeviceToDevice, st));
+           grad_scale, (const float*)(scratch + 1000), total_norm_out);
     return 0;
 }
 

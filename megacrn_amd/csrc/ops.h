@@ -798,10 +798,11 @@ __global__ void k_sumsq_stage2(const float* __restrict__ part, int nblk, float* 
 __global__ void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                             float bc1, float bc2_sqrt, float max_norm, float scale,
-                            const float* __restrict__ total_norm) {
+                            const float* __restrict__ total_norm, float* __restrict__ total_norm_out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float tn = total_norm[0];
+    if (i == 0 && total_norm_out) total_norm_out[0] = tn;   // (a 4-byte hipMemcpyAsync here cost ~100 us of queue idle per step)
     const float c = max_norm / (tn + 1e-6f);
     float coef = c > 1.f ? 1.f : c;        // torch.clamp(c, max=1): a NaN norm stays NaN like clip_grad_norm_ (fminf would drop it)
     float gi = g[i] * scale * coef;
