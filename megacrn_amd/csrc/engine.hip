@@ -179,8 +179,9 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
 // caller has to reason about (every side launch is joined back before the call returns its last kernel).
 struct Side {
     hipStream_t st = nullptr;
-    hipEvent_t ready[4], done[4], join, fork;    // plane sets: (update, gate) x (even, odd cell of the BPTT loop)
-    bool ok = false, pending[4] = {false, false, false, false}, any = false;
+    static const int NSLOT = 6;                  // plane sets: (update, gate) x NPAIR cells of the BPTT loop in flight
+    hipEvent_t ready[NSLOT], done[NSLOT], join, fork;
+    bool ok = false, pending[NSLOT] = {false, false, false, false, false, false}, any = false;
 };
 static Side g_side;
 static bool g_use_side = true;
@@ -189,7 +190,7 @@ static int side_init() {
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CK(hipStreamCreateWithPriority(&g_side.st, hipStreamNonBlocking, lo));     // lowest priority: fills idle CUs (same priority measured: no change)
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < Side::NSLOT; ++i) {
         CK(hipEventCreateWithFlags(&g_side.ready[i], hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming));
     }
@@ -211,7 +212,7 @@ static int side_join(hipStream_t st) {
         CK(hipEventRecord(g_side.join, g_side.st));
         CK(hipStreamWaitEvent(st, g_side.join, 0));
         g_side.any = false;
-        for (int i = 0; i < 4; ++i) g_side.pending[i] = false;
+        for (int i = 0; i < Side::NSLOT; ++i) g_side.pending[i] = false;
     }
     return 0;
 }
@@ -219,7 +220,7 @@ static int side_join(hipStream_t st) {
 // error paths: forget pending fork/join state (the caller's next call starts clean)
 static void side_reset() {
     g_side.any = false;
-    for (int i = 0; i < 4; ++i) g_side.pending[i] = false;
+    for (int i = 0; i < Side::NSLOT; ++i) g_side.pending[i] = false;
 }
 // The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
 // thread per process (the launch model of bench.py / megacrn_amd.train: one process per GPU).
@@ -1001,7 +1002,10 @@ struct ModelPlan {
     float *Zdec, *Ydec, *zr_d, *hc_d;
     float *q_rows, *att_rows; int* ind_rows;
     float *dP, *dQ, *dTu, *dTg;
-    float *dP2, *dQ2;              // second plane-set pair: cells alternate, so the helper stream may lag one cell behind
+    // NPAIR plane-set pairs (pair 0 = dP, dQ): the cells of a BPTT loop rotate through them, so the helper stream's
+    // adjacency-gradient launch may lag NPAIR - 1 cells behind the main stream before the main stream has to wait
+    static const int NPAIR = 3;
+    float *dPp[NPAIR], *dQp[NPAIR];
     float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
     float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
     bool defer_ds;
@@ -1073,8 +1077,8 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     size_t zmax = (size_t)(P.se.ZT > P.sd.ZT ? P.se.ZT : P.sd.ZT);
     P.dP = b.take<float>(zmax);
     P.dQ = b.take<float>(zmax);
-    P.dP2 = b.take<float>(zmax);
-    P.dQ2 = b.take<float>(zmax);
+    P.dPp[0] = P.dP; P.dQp[0] = P.dQ;
+    for (int i = 1; i < ModelPlan::NPAIR; ++i) { P.dPp[i] = b.take<float>(zmax); P.dQp[i] = b.take<float>(zmax); }
     {
         size_t pmax = (size_t)(P.se.PS > P.sd.PS ? P.se.PS : P.sd.PS);
         P.dTu = b.take<float>(pmax);
@@ -1414,9 +1418,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         for (int t = To - 1; t >= 0; --t) {
             const bool last = t == To - 1;
             const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
-            const int pair = t & 1;
-            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : (pair ? P.dP2 : P.dP);
-            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : (pair ? P.dQ2 : P.dQ);
+            const int pair = t % ModelPlan::NPAIR;
+            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dPp[pair];
+            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQp[pair];
             if (last) {
                 LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
                        (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
@@ -1483,11 +1487,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         bool xu = false, xg = false;
         for (int t = Ti - 1; t >= 0; --t) {
             const bool first = t == Ti - 1;
-            const int pair = t & 1;
-            float* dPt = pair ? P.dP2 : P.dP;
-            float* dQt = pair ? P.dQ2 : P.dQ;
+            const int pair = t % ModelPlan::NPAIR, prev = (t + 1) % ModelPlan::NPAIR;   // (the cell processed just before: t + 1)
+            float* dPt = P.dPp[pair];
+            float* dQt = P.dQp[pair];
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
-                CKI(cell_bwd_ca(se, pair ? P.dP : P.dP2, pair ? P.dQ : P.dQ2, P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
+                CKI(cell_bwd_ca(se, P.dPp[prev], P.dQp[prev], P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
                                 P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
                                 P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
