@@ -67,7 +67,7 @@ def pmc_traffic(config_name, dtype, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 per
     MI355X_MICROARCH.md).  None when no profile of this config is committed."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"traffic_{config_name}.json")
         if os.path.exists(path):
             break
@@ -114,34 +114,76 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(cfg, sample_B, sample_T, steps, nthr):
-    """The numpy oracle (a port of the reference CPU path) timed on this host on a bounded sample: `sample_B` samples,
-    sequences of `sample_T` (<= T) steps, `nthr` BLAS threads.  Returns samples/s scaled to the full sequence length."""
+def cpu_baseline_numpy(cfg, sample_B, sample_T, nthr):
+    """The numpy oracle (the parity checker) timed on a bounded sample: one warm step on 2 samples, then one timed train
+    step of `sample_B` samples x `sample_T` (<= T) sequence steps on `nthr` BLAS threads; samples/s scaled to T."""
     from oracle import megacrn_oracle as O
+    from threadpoolctl import threadpool_limits
     N, T, H = cfg["N"], cfg["T"], cfg["H"]
     P = O.init_params(N, rnn_units=H, mem_num=cfg["M"], mem_dim=cfg["D"], seed=0)
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((sample_B, sample_T, N, 1)).astype(np.float32)
-    yc = rng.random((sample_B, sample_T, N, 1)).astype(np.float32)
-    y = rng.standard_normal((sample_B, sample_T, N, 1)).astype(np.float32)
+    mk = lambda b: (rng.standard_normal((b, sample_T, N, 1)).astype(np.float32), rng.random((b, sample_T, N, 1)).astype(np.float32),
+                    rng.standard_normal((b, sample_T, N, 1)).astype(np.float32))
     opt = O.Adam(P)
-    from threadpoolctl import threadpool_limits
+    teacher = [i % 2 == 0 for i in range(sample_T)]
     with threadpool_limits(limits=nthr):
+        O.train_step(P, opt, *mk(min(2, sample_B)), teacher, SC_MEAN, SC_STD)              # warm: BLAS pool, page-in
+        x, yc, y = mk(sample_B)
         t = time.perf_counter()
-        for s in range(steps):
-            O.train_step(P, opt, x, yc, y, [(s + i) % 2 == 0 for i in range(sample_T)], SC_MEAN, SC_STD)
+        O.train_step(P, opt, x, yc, y, teacher, SC_MEAN, SC_STD)
         dt = time.perf_counter() - t
-    return sample_B * steps / dt * (sample_T / T), dt
+    return sample_B / dt * (sample_T / T), dt
+
+
+def cpu_baseline_torch(cfg, sample_B, sample_T, nthr):
+    """The reference's own ATen op sequence on the host cores (oracle/megacrn_torch_cpu.py: einsum / cat / sigmoid ...,
+    autograd backward, clip_grad_norm_, torch Adam - SURVEY.md 8(d)), one warm step on 2 samples then one timed train
+    step of `sample_B` samples x `sample_T` sequence steps at `nthr` threads; samples/s scaled linearly to T."""
+    from oracle import megacrn_oracle as O
+    from oracle import megacrn_torch_cpu as TC
+    N, T, H = cfg["N"], cfg["T"], cfg["H"]
+    P = TC.make_params(O.init_params(N, rnn_units=H, mem_num=cfg["M"], mem_dim=cfg["D"], seed=0))
+    opt = torch.optim.Adam(list(P.values()), lr=0.01, eps=1e-3)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda b: (torch.randn(b, sample_T, N, 1, generator=g), torch.rand(b, sample_T, N, 1, generator=g),
+                    torch.randn(b, sample_T, N, 1, generator=g))
+    teacher = [i % 2 == 0 for i in range(sample_T)]
+    prev = torch.get_num_threads()
+    torch.set_num_threads(nthr)
+    try:
+        TC.train_step(P, opt, *mk(min(2, sample_B)), teacher, SC_MEAN, SC_STD)             # warm
+        x, yc, y = mk(sample_B)
+        t = time.perf_counter()
+        TC.train_step(P, opt, x, yc, y, teacher, SC_MEAN, SC_STD)
+        dt = time.perf_counter() - t
+    finally:
+        torch.set_num_threads(prev)
+    return sample_B / dt * (sample_T / T), dt
 
 
 def cpu_sample(cfg, B, budget_flops):
-    """(samples, sequence length) of the CPU leg so that one train step stays within `budget_flops` algorithmic flops:
-    as many whole samples as fit (at most B/4), else one sample with a shortened sequence (cost is linear in T)."""
+    """(samples, sequence length) of a CPU leg so that one train step stays within `budget_flops` algorithmic flops:
+    the full batch when it fits, else as many whole samples as fit, else one sample with a shortened sequence."""
     per_sample = 3.0 * alg_flops_forward(cfg, 1)
     nb = int(budget_flops // per_sample)
     if nb >= 1:
-        return min(nb, max(1, B // 4)), cfg["T"]
+        return min(nb, B), cfg["T"]
     return 1, max(1, min(cfg["T"], int(budget_flops // (per_sample / cfg["T"]))))
+
+
+def launch_cmd(gpus, port, argv):
+    """torchrun command line of the N ranks (one per GPU, rendezvous on 127.0.0.1: the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_env():
+    """Environment of the ranks.  HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC;
+    with the legacy mode RCCL's cross-process buffer registration fails (hipIpcGetMemHandle: invalid argument).  The
+    images export it already; set here only if the caller's environment lacks it."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
 
 
 def self_launch(args):
@@ -153,11 +195,91 @@ def self_launch(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(launch_cmd(args.gpus, port, sys.argv[1:]), env=launch_env())
+
+
+def prop_kernel_name(cfg, dtype):
+    return ("mcrn::gemm_bf16(_pp)_kernel<BM,BN,..,BTR=true,ROLE=1> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
+            "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 352 and dtype == "bf16x3" else
+            "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
+
+
+def time_role(tr, batch, role, nrep):
+    """HIP events around every launch of GEMM role `role` (on the stream it is launched on) during `nrep` real train steps."""
+    from megacrn_amd._lib import lib, check
+    check(lib.mcrn_prof_begin(role), "prof_begin")
+    for _ in range(nrep):
+        tr.train_step(*batch)
+    ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+    torch.cuda.synchronize()
+    check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
+    return ms.value, n.value, af.value, ef.value
+
+
+def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
+    """`roofline` object of the forward K-hop propagation (the dominant kernel north_star names)."""
+    ms, n, af, _ = time_role(tr, batch, 1, nrep)
+    launch_s = ms * 1e-3 / n
+    alg_flops = af / n
+    alg_bytes = propagation_alg_bytes(cfg, B, dtype)
+    ai = alg_flops / alg_bytes
+    ridge = PEAK[dtype] / HBM_PEAK
+    frac_mfma, frac_hbm = alg_flops / launch_s / PEAK[dtype], alg_bytes / launch_s / HBM_PEAK
+    bound = "mfma" if ai >= ridge else "hbm"
+    return {"bound": bound, "kernel": prop_kernel_name(cfg, dtype) + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
+            "achieved": round(alg_flops / launch_s / 1e12, 3) if bound == "mfma" else round(alg_bytes / launch_s / 1e9, 1),
+            "peak": round(PEAK[dtype] / 1e12, 1) if bound == "mfma" else HBM_PEAK / 1e9,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 5),
+            "traffic": pmc_traffic(config_name, dtype, cfg["N"]),
+            "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
+            "frac_of_mfma_peak": round(frac_mfma, 5), "frac_of_hbm_peak": round(frac_hbm, 5),
+            "achieved_tflops": round(alg_flops / launch_s / 1e12, 3), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 1),
+            "note": "bound chosen by algorithmic intensity (flops / algorithmic bytes) vs the ridge peak_flops / 8 TB/s; "
+                    "achieved = algorithmic flops (2 N^2 B C per support and hop, true channel count) or algorithmic bytes "
+                    "(supports + input plane + propagated planes, once each) / HIP-event launch time; traffic = corrected "
+                    "PMC HBM bytes per launch (profiles/, tools/pmc_traffic.sh)"
+                    + ("; bf16x3 issues 3 bf16 MFMAs per product: its matrix-core ceiling is 833 TF" if dtype == "bf16x3" else ""),
+            "avg_launch_us": round(1e3 * ms / n, 3), "launches": n,
+            "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes}
+
+
+def make_trainer(config_name, B, prec, device, rank):
+    import megacrn_amd
+    from megacrn_amd import _lib
+    from megacrn_amd.trainer import FlatTrainer
+    cfg = CONFIGS[config_name]
+    model = megacrn_amd.MegaCRN(num_nodes=cfg["N"], input_dim=1, output_dim=1, horizon=cfg["T"],
+                                rnn_units=cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(device).train()
+    model.precision = _lib.PRECISIONS[prec]
+    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+    batch = synth(cfg, B, 1234 + rank, device)
+    tr._prepare(batch[0])              # workspace + one-off GEMM tile autotune: never inside a timed region
+    return tr, batch
+
+
+def secondary_leg(device, steps=4, warmup=2):
+    """The north_star figure, driver-timed: forward N x N propagation at N = 1843 (EXPY-TKY shape, B = 32, T = 6, H = 32)
+    in the bf16-resident arithmetic, as a short extra run after the headline measurement (a few seconds)."""
+    name, prec = "expytky", "bf16"
+    cfg = CONFIGS[name]
+    B = cfg["B"]
+    tr, batch = make_trainer(name, B, prec, device, 0)
+    for _ in range(warmup):
+        tr.train_step(*batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(*batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=4)
+    return {"what": "forward K-hop propagation at N=1843 (BASELINE configs[3] shape, per-GPU batch 32), the kernel north_star "
+                    "sets the >= 40 % bf16-MFMA target on; measured in this same process after the headline run",
+            "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} mem={cfg['M']}x{cfg['D']} "
+                                   f"cheb_k=3, batch {B}, full train step"},
+            "dtype": prec, "value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 4),
+            "steps": steps, "warmup": warmup, "roofline": roof}
 
 
 def main():
@@ -172,22 +294,31 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"], help="default: per config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the N=1843 propagation leg of the default run")
     ap.add_argument("--roles", default="1,2,3,4,5,6", help="GEMM roles timed for gemm_roles (diagnostics)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
-    import megacrn_amd
+    import megacrn_amd  # noqa: F401
     from megacrn_amd import dp
-    from megacrn_amd._lib import lib, check
-    from megacrn_amd.trainer import FlatTrainer
+    from megacrn_amd._lib import lib
     import torch.distributed as dist
 
-    rank, local_rank, world = dp.init_from_env("nccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does)")
+    rank, local_rank, env_world = dp.init_from_env("nccl")
+    # what the process group itself reports - not the environment - plus an all-reduce of ones below: the line proves
+    # that RCCL connected `world` ranks
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus or env_world != world:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks (WORLD_SIZE={env_world}): "
+                         f"launch one rank per GPU (python bench.py --gpus N does)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)                       # RCCL all-reduce(sum) of ones = number of ranks that took part
+        ranks_seen = int(round(one.item()))
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["B"]
     if args.scaling == "strong":
@@ -197,15 +328,11 @@ def main():
 
     torch.manual_seed(1234)            # identical init on every rank (also broadcast by the trainer)
     dp.seed_curriculum(1234)           # shared numpy stream: same teacher-forcing draws on all ranks
-    model = megacrn_amd.MegaCRN(num_nodes=cfg["N"], input_dim=1, output_dim=1, horizon=cfg["T"],
-                                rnn_units=cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(device).train()
-    from megacrn_amd import _lib
     # arithmetic: bf16x3 (fp32-equivalent, the 1e-4 parity mode) for the small graphs; the large graphs default to the
     # bf16-resident propagation mode (own stated tolerance, tests/test_gpu_parity.py::test_bf16_mode_*)
     prec = args.precision or ("bf16" if cfg["N"] >= 1024 else "bf16x3")
-    model.precision = _lib.PRECISIONS[prec]
-    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
-    x, ycov, y = synth(cfg, B, 1234 + rank, device)
+    tr, batch = make_trainer(args.config, B, prec, device, rank)
+    x, ycov, y = batch
     dtype = prec
 
     def sync_all():
@@ -213,7 +340,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tr._prepare(x)                     # workspace + one-off GEMM tile autotune: never inside the timed region
     loss = torch.zeros((), device=device)
     for _ in range(args.warmup):
         loss = tr.train_step(x, ycov, y)
@@ -234,68 +360,48 @@ def main():
     roles, roof = {}, None
     if not args.no_roofline:
         for role in [int(r) for r in args.roles.split(",") if r]:
-            check(lib.mcrn_prof_begin(role), "prof_begin")
-            tr.train_step(x, ycov, y)
-            ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
-            torch.cuda.synchronize()
-            check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
-            roles[ROLE_NAMES[role]] = dict(ms_per_step=round(ms.value, 4), launches_per_step=n.value,
-                                           avg_us=round(1e3 * ms.value / max(n.value, 1), 3),
-                                           alg_tflops=round(af.value / (ms.value * 1e-3) / 1e12, 2) if ms.value else 0,
-                                           exec_tflops=round(ef.value / (ms.value * 1e-3) / 1e12, 2) if ms.value else 0)
+            ms, n, af, ef = time_role(tr, batch, role, 1)
+            roles[ROLE_NAMES[role]] = dict(ms_per_step=round(ms, 4), launches_per_step=n,
+                                           avg_us=round(1e3 * ms / max(n, 1), 3),
+                                           alg_tflops=round(af / (ms * 1e-3) / 1e12, 2) if ms else 0,
+                                           exec_tflops=round(ef / (ms * 1e-3) / 1e12, 2) if ms else 0)
         sync_all()
         # dominant kernel of the path = forward K-hop propagation (north_star): average over several steps
-        check(lib.mcrn_prof_begin(1), "prof_begin")
-        nrep = 5
-        for _ in range(nrep):
-            tr.train_step(x, ycov, y)
-        ms, n, af, ef = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
-        torch.cuda.synchronize()
-        check(lib.mcrn_prof_end(C.byref(ms), C.byref(n), C.byref(af), C.byref(ef)), "prof_end")
-        kname = ("mcrn::gemm_bf16_kernel<BM,BN,..,BTR=true> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
-                 "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 352 and dtype == "bf16x3" else
-                 "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
-        launch_s = ms.value * 1e-3 / n.value
-        alg_flops = af.value / n.value
-        alg_bytes = propagation_alg_bytes(cfg, B, dtype)
-        ai = alg_flops / alg_bytes
-        ridge = PEAK[dtype] / HBM_PEAK
-        frac_mfma, frac_hbm = alg_flops / launch_s / PEAK[dtype], alg_bytes / launch_s / HBM_PEAK
-        bound = "mfma" if ai >= ridge else "hbm"
-        roof = {"bound": bound, "kernel": kname + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
-                "achieved": round(alg_flops / launch_s / 1e12, 3) if bound == "mfma" else round(alg_bytes / launch_s / 1e9, 1),
-                "peak": round(PEAK[dtype] / 1e12, 1) if bound == "mfma" else HBM_PEAK / 1e9,
-                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 5),
-                "traffic": pmc_traffic(args.config, dtype, cfg["N"]),
-                "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
-                "frac_of_mfma_peak": round(frac_mfma, 5), "frac_of_hbm_peak": round(frac_hbm, 5),
-                "achieved_tflops": round(alg_flops / launch_s / 1e12, 3), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 1),
-                "note": "bound chosen by algorithmic intensity (flops / algorithmic bytes) vs the ridge peak_flops / 8 TB/s; "
-                        "achieved = algorithmic flops (2 N^2 B C per support and hop, true channel count) or algorithmic bytes "
-                        "(supports + input plane + propagated planes, once each) / HIP-event launch time; traffic = corrected "
-                        "PMC HBM bytes per launch (profiles/r2, tools/pmc_traffic.sh)"
-                        + ("; bf16x3 issues 3 bf16 MFMAs per product: its matrix-core ceiling is 833 TF" if dtype == "bf16x3" else ""),
-                "avg_launch_us": round(1e3 * ms.value / n.value, 3), "launches": n.value,
-                "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes}
+        roof = roofline_of(tr, batch, cfg, args.config, B, dtype)
+        # the kernel that takes the most time per step, when it is not the propagation
+        if roles:
+            top = max(roles.items(), key=lambda kv: kv[1]["ms_per_step"])
+            roof["largest_role_by_time"] = {"role": top[0], **top[1]}
         sync_all()
+
+    secondary = None
+    if rank == 0 and world == 1 and args.config == "metrla" and not args.no_secondary and not args.no_roofline:
+        del tr
+        torch.cuda.empty_cache()
+        secondary = secondary_leg(device)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # bounded sample (about 10-30 s of CPU work in total): a flop budget per leg - all useful cores, and ONE thread
-        # (the reference trainer pins one thread, model/traintest_MegaCRN.py:255-261); graphs too large for even one
-        # full sample within the budget run a shortened sequence and are scaled linearly to T
-        nthr = min(32, os.cpu_count() or 1)      # more BLAS threads than this only slows these small matrices
-        sB, sT = cpu_sample(cfg, B, 2.0e12)
-        v, secs = cpu_baseline(cfg, sB, sT, 1, nthr)
-        s1, t1 = cpu_sample(cfg, B, 0.25e12)
-        v1, secs1 = cpu_baseline(cfg, s1, t1, 1, 1)
+        # bounded sample (about 10-30 s of CPU work in total).  Main figure: the reference's own ATen op sequence on the host
+        # (oracle/megacrn_torch_cpu.py) at min(cores, 32) threads and at ONE thread (what the reference trainer pins,
+        # model/traintest_MegaCRN.py:255-261): the full batch when a step fits ~1e12 algorithmic flops per leg, else as many
+        # samples / sequence steps as fit (scaled linearly).  Second figure: the numpy port (the parity oracle) on one thread.
+        nthr = min(32, os.cpu_count() or 1)
+        sB, sT = cpu_sample(cfg, B, 1.4e12)
+        v, secs = cpu_baseline_torch(cfg, sB, sT, nthr)
+        s1, t1 = cpu_sample(cfg, B, 0.7e12)
+        v1, secs1 = cpu_baseline_torch(cfg, s1, t1, 1)
+        sn, tn = cpu_sample(cfg, B, 0.25e12)
+        vn, secsn = cpu_baseline_numpy(cfg, sn, tn, 1)
         cpu = {"value": round(v, 4), "unit": "samples/s", "cores": nthr, "kind": "port",
-               "value_1thread": round(v1, 4), "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
-               "sample": f"oracle/megacrn_oracle.py (numpy port of the reference CPU path), one full train step of the same "
-                         f"{cfg['label']} workload: {sB} of the {B} samples x {sT} of {cfg['T']} sequence steps on {nthr} BLAS "
+               "value_1thread": round(v1, 4), "value_numpy_port_1thread": round(vn, 4),
+               "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
+               "sample": f"oracle/megacrn_torch_cpu.py (the reference's ATen op sequence on PyTorch-CPU, autograd backward, "
+                         f"clip_grad_norm_, torch Adam), warm (one untimed step on 2 samples first), one full train step of the "
+                         f"same {cfg['label']} workload: {sB} of the {B} samples x {sT} of {cfg['T']} sequence steps on {nthr} "
                          f"threads ({secs:.1f} s); value_1thread: {s1} samples x {t1} steps on 1 thread ({secs1:.1f} s); "
-                         f"both scaled linearly to the full sequence length"}
+                         f"value_numpy_port_1thread: oracle/megacrn_oracle.py, {sn} samples x {tn} steps ({secsn:.1f} s); "
+                         f"all scaled linearly to the full sequence length"}
 
     if rank == 0:
         gb = B * world
@@ -305,7 +411,7 @@ def main():
             "metric": "training samples/sec (12-step seq2seq)" if cfg["T"] == 12 else "training samples/sec (6-step seq2seq)",
             "value": round(val, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
-            "backend": "rccl" if world > 1 else "single-process", "world_size": world,
+            "backend": "rccl" if world > 1 else "single-process", "world_size": world, "rccl_ranks_seen": ranks_seen,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} "
                                    f"mem={cfg['M']}x{cfg['D']} cheb_k=3, per-GPU batch {B}, full train step "
@@ -317,6 +423,8 @@ def main():
         if roof:
             out["roofline"] = roof
             out["gemm_roles"] = roles
+        if secondary:
+            out["secondary"] = secondary
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

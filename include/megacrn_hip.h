@@ -21,6 +21,9 @@
  *  - Return value: 0 on success, otherwise a hipError_t (>0) or
  *    MCRN_EINVAL (-1) for unsupported arguments; mcrn_last_error() returns a
  *    static message.
+ *  - Process model: ONE host thread and ONE device per process (one process per GPU).  The library keeps a
+ *    process-wide helper stream, tile cache and profiler; every compute entry point refuses (MCRN_EINVAL) a call
+ *    that arrives while another host thread is inside the library, or on a different device than the first call.
  *  - Supported: cheb_k in {2,3}; any B,N,H,input/output/ycov dims >= 1;
  *    num_layers == 1 in the fused model entry points (multi-layer models are
  *    composed from mcrn_cell_* by the host module).
@@ -208,6 +211,12 @@ int mcrn_prof_begin(int role);
 int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream);
 int mcrn_autotune_entries(void);
 int mcrn_autotune_clear(void);
+/* The tile table as a flat int32 record list ({kind, nkey, key words..., cfg} per entry).  export returns the number of
+ * words the table needs and fills `buf` when `cap` is large enough (call with NULL/0 first); import REPLACES the table.
+ * Data-parallel ranks tune independently and timing noise may choose different tiles (different fp32 summation
+ * orders): rank 0 exports, every other rank imports, so all replicas run identical kernels (megacrn_amd/trainer.py). */
+long long mcrn_autotune_export(int* buf, long long cap);
+int mcrn_autotune_import(const int* buf, long long n);
 /* tuning hook: force GEMM tile configuration 0..6 for every launch (-1 = automatic) */
 int mcrn_set_gemm_cfg(int cfg);
 /* ablation bits for the GEMM main loop (results are WRONG when non-zero; tools/ablate.py only) */

@@ -23,7 +23,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_eval_metrics", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
+    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_eval_metrics", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_autotune_export", "mcrn_autotune_import", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
 ]
 
 
@@ -118,6 +118,10 @@ def _load():
     lib.mcrn_model_autotune.argtypes = [C.POINTER(Dims), vp, sz, vp]
     lib.mcrn_autotune_entries.restype = i
     lib.mcrn_autotune_clear.restype = i
+    lib.mcrn_autotune_export.restype = ll
+    lib.mcrn_autotune_export.argtypes = [C.POINTER(C.c_int), ll]
+    lib.mcrn_autotune_import.restype = i
+    lib.mcrn_autotune_import.argtypes = [C.POINTER(C.c_int), ll]
     lib.mcrn_set_debug.restype = i
     lib.mcrn_set_debug.argtypes = [i]
     lib.mcrn_set_gemm_cfg.restype = i
@@ -143,6 +147,19 @@ def default_precision() -> int:
 def set_precision(name_or_id) -> None:
     v = PRECISIONS[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
     check(lib.mcrn_set_precision(v), "mcrn_set_precision")
+
+
+def autotune_export() -> list:
+    """The tile table chosen by mcrn_model_autotune as a list of ints (see include/megacrn_hip.h)."""
+    n = lib.mcrn_autotune_export(None, 0)
+    buf = (C.c_int * max(n, 1))()
+    lib.mcrn_autotune_export(buf, n)
+    return list(buf[:n])
+
+
+def autotune_import(words) -> None:
+    arr = (C.c_int * max(len(words), 1))(*words)
+    check(lib.mcrn_autotune_import(arr, len(words)), "mcrn_autotune_import")
 
 
 def check(rc: int, what: str) -> None:

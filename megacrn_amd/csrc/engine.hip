@@ -17,6 +17,8 @@
 #include <map>
 #include <algorithm>
 #include <stdlib.h>
+#include <atomic>
+#include <vector>
 
 #include "../../include/megacrn_hip.h"
 #include "gemm_f32.h"
@@ -64,6 +66,37 @@ static int g_launches = 0;
         ++g_launches;                                                                         \
         CK(hipGetLastError());                                                                \
     } while (0)
+
+// ---- process-global state guard ------------------------------------------------------------------
+// The library keeps ONE helper stream, tile cache, profiler and arithmetic mode per process:
+// its launch model is one process per GPU with one host thread driving it.  A second host thread inside the
+// library at the same time, or a call on a second device, would silently share that state - both are refused.
+static std::atomic<int> g_busy{0};
+static int g_device = -1;
+struct CallGuard {
+    bool entered = false;
+    int enter() {
+        if (g_busy.exchange(1, std::memory_order_acquire) != 0) {
+            // (g_err is shared too: the message is best-effort, the return code is what counts)
+            snprintf(g_err, sizeof g_err, "libmegacrn_hip: concurrent call from a second host thread (one host thread per process)");
+            return MCRN_EINVAL;
+        }
+        entered = true;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof g_err, "hipGetDevice failed"); return MCRN_EINVAL; }
+        if (g_device < 0) g_device = dev;
+        else if (dev != g_device) {
+            snprintf(g_err, sizeof g_err, "libmegacrn_hip: called on device %d after device %d (one device per process: the tile cache, "
+                     "helper stream and stream-K workspaces belong to the first device)", dev, g_device);
+            return MCRN_EINVAL;
+        }
+        return 0;
+    }
+    ~CallGuard() { if (entered) g_busy.store(0, std::memory_order_release); }
+};
+#define ENTER()                                                                               \
+    CallGuard guard__;                                                                        \
+    do { int r__ = guard__.enter(); if (r__) return r__; } while (0)
 
 // ---- live profiler: HIP events around every launch of one role (bench.py roofline leg) ---------
 struct Prof {
@@ -579,9 +612,14 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
+    const bool ds_small_path = !u.defer && small && aligned16(X) && ds_small_enabled();
+    if (cell_ds && cell_ds->nseg > 0 && !ds_small_path)
+        // the update call of this cell queued its d1t x0^T / e2 x1^T segments for a merged launch; the gate call must
+        // take the same branch, or those contributions to dS would be silently dropped
+        FAIL("adjacency gradient: the two AGCN calls of a cell chose different paths (%d segments queued)", cell_ds->nseg);
     if (u.defer) {
         // nothing here: d1t / e2 stay in this call's plane set and are consumed by the deferred launch
-    } else if (small && aligned16(X) && ds_small_enabled()) {   // output-stationary adjacency-gradient kernel (prop_small.h)
+    } else if (ds_small_path) {   // output-stationary adjacency-gradient kernel (prop_small.h)
         // The two AGCN calls of a cell (update first, gate second) share ONE launch: every workgroup adds both calls'
         // products to its slab partial while it sits in the accumulators, so the slab is read and written once per cell
         // instead of once per call (the slab read-modify-write was ~1/3 of this kernel's HBM bytes, profiles/r1).
@@ -682,9 +720,10 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
 // ---- deferred weight gradient: slabs += X_all^T dY_all over T steps -------------------------------
 // The streaming kernel (wgrad_stream.h) takes every shape of the library's bf16x3 sessions; exact-fp32 sessions and odd
 // widths keep the tiled GEMM.  Returns the number of slabs written through *nslab.
-static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* dYall, long long step_stride) {
+static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* dYall, long long step_stride, int T) {
     static const bool off = getenv("MCRN_WGRAD_STREAM") && atoi(getenv("MCRN_WGRAD_STREAM")) == 0;
-    return !off && g_precision == MCRN_BF16X3 && wgrad_stream_ok(s.G, s.Cp, O) && aligned16(Xall) && aligned16(dYall) &&
+    // T > NSLAB_W (one slab per step at least): the tiled split-K GEMM has no such limit
+    return !off && T <= NSLAB_W && g_precision == MCRN_BF16X3 && wgrad_stream_ok(s.G, s.Cp, O) && aligned16(Xall) && aligned16(dYall) &&
            ((step_stride | s.PS) & 3) == 0;
 }
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
@@ -692,7 +731,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
     // ones != null: the caller wants the column sums of dY (bias gradient) as row G*Cp of the slabs when the streaming
     // kernel runs (*ones = true), and computes them itself otherwise
     if (ones) *ones = false;
-    if (wgrad_streams(s, O, Xall, dYall, step_stride)) {
+    if (wgrad_streams(s, O, Xall, dYall, step_stride, T)) {
         WgradP q;
         q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
         q.dY = dYall; q.O = O; q.slabs = slabs; q.ones = ones ? 1 : 0;
@@ -1648,6 +1687,7 @@ int mcrn_debug_timeline(void* host_out, size_t bytes) {
 #endif
 
 int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* stream) {
+    ENTER();
     CKI(check_dims(d));
     if (!ws || ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("autotune: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1693,8 +1733,52 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
     (void)hipFree(buf);
     return rc;
 }
-int mcrn_autotune_entries(void) { return (int)g_tuned.size(); }
-int mcrn_autotune_clear(void) { g_tuned.clear(); return 0; }
+int mcrn_autotune_entries(void) { return (int)(g_tuned.size() + g_tuned_bf16.size()); }
+int mcrn_autotune_clear(void) { g_tuned.clear(); g_tuned_bf16.clear(); return 0; }
+// Tile table as a flat int32 record list: {kind, nkey, key..., cfg}.  Data-parallel ranks tune independently (timing noise
+// can pick different tiles, hence different fp32 summation orders); rank 0 exports, the others import (dp / bench.py).
+long long mcrn_autotune_export(int* buf, long long cap) {
+    std::vector<int> out;
+    for (const auto& kv : g_tuned) {
+        const int* k = reinterpret_cast<const int*>(&kv.first);
+        const int nk = (int)(sizeof(TuneKey) / sizeof(int));
+        out.push_back(0); out.push_back(nk);
+        for (int i = 0; i < nk; ++i) out.push_back(k[i]);
+        out.push_back(kv.second);
+    }
+    for (const auto& kv : g_tuned_bf16) {
+        const int* k = reinterpret_cast<const int*>(&kv.first);
+        const int nk = (int)(sizeof(Bf16Key) / sizeof(int));
+        out.push_back(1); out.push_back(nk);
+        for (int i = 0; i < nk; ++i) out.push_back(k[i]);
+        out.push_back(kv.second);
+    }
+    if (buf && cap >= (long long)out.size()) memcpy(buf, out.data(), out.size() * sizeof(int));
+    return (long long)out.size();
+}
+int mcrn_autotune_import(const int* buf, long long n) {
+    if (!buf || n < 0) FAIL("autotune_import: bad arguments");
+    std::map<TuneKey, int> a;
+    std::map<Bf16Key, int> b;
+    long long i = 0;
+    while (i < n) {
+        if (i + 2 > n) FAIL("autotune_import: truncated record");
+        const int kind = buf[i], nk = buf[i + 1];
+        const int want = kind == 0 ? (int)(sizeof(TuneKey) / sizeof(int)) : kind == 1 ? (int)(sizeof(Bf16Key) / sizeof(int)) : -1;
+        if (nk != want || i + 2 + nk + 1 > n) FAIL("autotune_import: malformed record at word %lld", i);
+        const int cfg = buf[i + 2 + nk];
+        if (kind == 0) {
+            if (cfg < 0 || cfg >= NCFG) FAIL("autotune_import: tile configuration %d out of range", cfg);
+            TuneKey k; memcpy(&k, buf + i + 2, sizeof k); a[k] = cfg;
+        } else {
+            if (cfg < 0 || cfg >= NCFG_BF16) FAIL("autotune_import: bf16 tile configuration %d out of range", cfg);
+            Bf16Key k; memcpy(&k, buf + i + 2, sizeof k); b[k] = cfg;
+        }
+        i += 2 + nk + 1;
+    }
+    g_tuned.swap(a); g_tuned_bf16.swap(b);
+    return 0;
+}
 int mcrn_set_precision(int precision) {
     if (precision != MCRN_F32 && precision != MCRN_BF16X3 && precision != MCRN_BF16) FAIL("unsupported precision %d", precision);
     g_precision = precision == MCRN_BF16 ? MCRN_BF16X3 : precision;   // the stand-alone ops have no bf16-resident form
@@ -1738,6 +1822,7 @@ size_t mcrn_model_workspace_bytes(const mcrn_dims_t* d) {
 int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float* x, const float* ycov,
                        const float* labels, const int* teacher, void* ws, size_t ws_bytes, float* output,
                        float* h_att, float* query, float* pos, float* neg, void* stream) {
+    ENTER();
     CKI(check_dims(d));
     if (!p || !x || !ws || !output || !h_att || !query || !pos || !neg) FAIL("mcrn_model_forward: NULL argument");
     if (d->ycov_dim > 0 && !ycov) FAIL("mcrn_model_forward: ycov is NULL");
@@ -1753,6 +1838,7 @@ int mcrn_model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const float
 int mcrn_model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const int* teacher, const float* d_output,
                         const float* d_hatt, const float* d_query, const float* d_pos, const float* d_neg, void* ws,
                         size_t ws_bytes, const mcrn_grads_t* grads, void* stream) {
+    ENTER();
     CKI(check_dims(d));
     if (!p || !d_output || !ws || !grads) FAIL("mcrn_model_backward: NULL argument");
     if (ws_bytes < mcrn_model_workspace_bytes(d)) FAIL("workspace too small");
@@ -1772,6 +1858,7 @@ size_t mcrn_supports_workspace_bytes(int N, int M, int D) {
 }
 int mcrn_supports_forward(int N, int M, int D, const float* We1, const float* We2, const float* Mem, void* ws,
                           size_t ws_bytes, float* g1, float* g2, void* stream) {
+    ENTER();
     if (N < 1 || M < 1 || D < 1) FAIL("supports: bad sizes");
     if (ws_bytes < mcrn_supports_workspace_bytes(N, M, D)) FAIL("workspace too small");
     Bump b{(char*)ws, 0};
@@ -1782,6 +1869,7 @@ int mcrn_supports_forward(int N, int M, int D, const float* We1, const float* We
 int mcrn_supports_backward(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
                            const float* dg1, const float* dg2, void* ws, size_t ws_bytes, float* dWe1, float* dWe2,
                            float* dMem, void* stream) {
+    ENTER();
     if (ws_bytes < mcrn_supports_workspace_bytes(N, M, D)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Bump b{(char*)ws, 0};
@@ -1803,6 +1891,7 @@ size_t mcrn_agcn_workspace_bytes(int B, int N, int C, int O, int cheb_k) {
 }
 int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, const float* s1, const float* s2,
                       const float* W, const float* bias, void* ws, size_t ws_bytes, float* y, void* stream) {
+    ENTER();
     if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
     if (B < 1 || N < 1 || C < 1 || O < 1) FAIL("agcn: bad sizes");
     if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
@@ -1824,6 +1913,7 @@ int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, co
 int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, const float* s1, const float* s2,
                        const float* W, void* ws, size_t ws_bytes, float* dx, float* ds1, float* ds2, float* dW,
                        float* db, void* stream) {
+    ENTER();
     if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
     if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1857,6 +1947,7 @@ size_t mcrn_cell_workspace_bytes(int B, int N, int din, int H, int cheb_k) {
 int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, const float* h, const float* s1,
                       const float* s2, const float* gate_w, const float* gate_b, const float* update_w,
                       const float* update_b, void* ws, size_t ws_bytes, float* hn, void* stream) {
+    ENTER();
     if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
     if (B < 1 || N < 1 || din < 0 || H < 1) FAIL("cell: bad sizes");
     if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
@@ -1881,6 +1972,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
                        const float* gate_w, const float* update_w, void* ws, size_t ws_bytes, float* dx, float* dh,
                        float* ds1, float* ds2, float* dgate_w, float* dgate_b, float* dupdate_w, float* dupdate_b,
                        void* stream) {
+    ENTER();
     (void)gate_w; (void)update_w;
     if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
     if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
@@ -1921,6 +2013,7 @@ size_t mcrn_memory_workspace_bytes(int B, int N, int H, int M, int D) {
 int mcrn_memory_forward(int B, int N, int H, int M, int D, const float* h, const float* Mem, const float* Wq,
                         void* ws, size_t ws_bytes, float* value, float* query, float* pos, float* neg, int* ind,
                         void* stream) {
+    ENTER();
     if (B < 1 || N < 1 || H < 1 || M < 1 || D < 1) FAIL("memory: bad sizes");
     if (ws_bytes < mcrn_memory_workspace_bytes(B, N, H, M, D)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1933,6 +2026,7 @@ int mcrn_memory_forward(int B, int N, int H, int M, int D, const float* h, const
 int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, const float* Mem, const float* Wq,
                          const float* dvalue, const float* dquery, const float* dpos, const float* dneg, void* ws,
                          size_t ws_bytes, float* dh, float* dMem, float* dWq, void* stream) {
+    ENTER();
     (void)h;
     if (ws_bytes < mcrn_memory_workspace_bytes(B, N, H, M, D)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1955,6 +2049,7 @@ int mcrn_memory_backward(int B, int N, int H, int M, int D, const float* h, cons
 int mcrn_flat_clip_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                         float eps, int step, float max_norm, float grad_scale, float* scratch, float* total_norm_out,
                         void* stream) {
+    ENTER();
     if (!p || !g || !m || !v || !scratch || n < 1 || step < 1) FAIL("flat_clip_adam: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     int nblk = cdiv(n, 256 * 8);
@@ -1974,6 +2069,7 @@ int mcrn_loss_fwd_bwd(int B, int T, int N, int od, int D, const float* output, c
                       const float* query, const float* pos, const float* neg, float mean, float stdv, float lamb,
                       float lamb1, float margin, float* scratch, float* losses, float* d_output, float* d_query,
                       void* stream) {
+    ENTER();
     if (B < 1 || T < 1 || N < 1 || od < 1 || D < 1 || !output || !labels || !query || !pos || !neg || !scratch ||
         !losses || !d_output || !d_query)
         FAIL("loss: bad arguments");
@@ -1995,6 +2091,7 @@ int mcrn_eval_metrics(int B, int T, int N, int od, int D, const float* output, c
                       const float* query, const float* pos, const float* neg, float mean, float stdv, float lamb,
                       float lamb1, float margin, const int* horizons, int nh, float* scratch, float* acc,
                       void* stream) {
+    ENTER();
     if (B < 1 || T < 1 || N < 1 || od < 1 || D < 1 || !output || !labels || !query || !pos || !neg || !scratch || !acc ||
         nh < 0 || nh > 3 || (nh > 0 && !horizons))
         FAIL("eval_metrics: bad arguments");
@@ -2016,6 +2113,7 @@ int mcrn_eval_metrics(int B, int T, int N, int od, int D, const float* output, c
 // ---- GEMM test hook -----------------------------------------------------------------------------
 int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, const float* B, float* C, float alpha,
                   float beta, int nsplit, float* slabs, void* stream) {
+    ENTER();
     hipStream_t st = (hipStream_t)stream;
     GemmP p = gp();
     p.M = M; p.N = N; p.K = K;

@@ -55,6 +55,18 @@ def broadcast_flat(flat_p: torch.Tensor, group=None, src: int = 0) -> None:
     dist.broadcast(flat_p, src=src, group=group)
 
 
+def share_autotune(group=None, src: int = 0) -> None:
+    """Every rank adopts rank `src`'s GEMM tile table (mcrn_model_autotune times tiles on-device; noise could choose
+    different tiles - different fp32 summation orders - on different replicas).  No-op at world size 1."""
+    if world_size(group) == 1:
+        return
+    from . import _lib
+    box = [_lib.autotune_export() if rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    if rank(group) != src:
+        _lib.autotune_import(box[0])
+
+
 def seed_curriculum(seed: int) -> None:
     """The curriculum draw is one np.random.uniform() per decoder step for the whole batch
     (model/MegaCRN.py:189): every rank must consume the same stream, so all ranks use `seed`."""

@@ -233,9 +233,13 @@ class _ProjFn(torch.autograd.Function):
         dx, dW = torch.empty_like(x), torch.empty_like(W)
         st = _stream()
         check(lib.mcrn_gemm_f32(R, K, O, 0, 0, _p(dy), _p(W), _p(dx), 1.0, 0.0, 1, None, st), "proj dx")       # dy W
-        slabs = torch.empty(64 * O * K, device=x.device)
+        slabs = torch.empty(64 * O * max(K, 1), device=x.device)
         check(lib.mcrn_gemm_f32(O, K, R, 1, 0, _p(dy), _p(x), _p(dW), 1.0, 0.0, 64, _p(slabs), st), "proj dW")  # dy^T x
-        return dx, dW, dy.reshape(R, O).sum(0)
+        # bias gradient = dy^T 1, on the same GEMM (the ones vector is a fill, not arithmetic)
+        db = torch.empty(O, device=x.device)
+        ones = torch.ones(R, device=x.device)
+        check(lib.mcrn_gemm_f32(O, 1, R, 1, 0, _p(dy), _p(ones), _p(db), 1.0, 0.0, 64, _p(slabs), st), "proj db")
+        return dx, dW, db
 
 
 class _ModelFn(torch.autograd.Function):

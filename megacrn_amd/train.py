@@ -83,34 +83,14 @@ def synthetic_windows(num_samples, T, N, seed):
 
 
 # ---------------------------------------------------------------------------------------------
-# device-side metrics -- model/utils.py:126-160
-# ---------------------------------------------------------------------------------------------
-def _masked(y_pred, y_true, fn):
-    mask = (y_true != 0).float()
-    mask = mask / mask.mean()
-    loss = fn(y_pred, y_true) * mask
-    loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
-    return loss.mean()
-
-
-def masked_mae_loss(p, t):
-    return _masked(p, t, lambda a, b: torch.abs(a - b))
-
-
-def masked_mape_loss(p, t):
-    return _masked(p, t, lambda a, b: torch.abs((b - a) / b))
-
-
-def masked_mse_loss(p, t):
-    return _masked(p, t, lambda a, b: (b - a) ** 2)
-
-
-# ---------------------------------------------------------------------------------------------
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--dataset', type=str, choices=['METRLA', 'PEMSBAY'], default='METRLA')
     p.add_argument('--data_dir', type=str, default=None, help='directory with train/val/test.npz (default ../<dataset>)')
     p.add_argument('--synthetic', type=int, default=0, help='>0: generate this many synthetic training windows')
+    p.add_argument('--trainval_ratio', type=float, default=0.8, help='accepted for command-line parity; like the reference '
+                   '(:160, never read after parsing) it does not change the pre-split train/val/test.npz files')
+    p.add_argument('--val_ratio', type=float, default=0.125, help='accepted for command-line parity (:161, unused there too)')
     p.add_argument('--num_nodes', type=int, default=207)
     p.add_argument('--seq_len', type=int, default=12)
     p.add_argument('--horizon', type=int, default=12)
@@ -204,6 +184,12 @@ class Prefetcher:
             if self.slots[k] is None or any(p.shape != h.shape for p, h in zip(self.slots[k][0], host)):
                 pin = tuple(torch.empty(h.shape, dtype=torch.float32).pin_memory() for h in host)
                 dev = tuple(torch.empty(h.shape, dtype=torch.float32, device=self.device) for h in host)
+                # the blocks come from the caching allocator on the CONSUMER stream but are first written on the copy
+                # stream: order the copy stream behind whatever last used those blocks, and tell the allocator about
+                # the second stream so that a dropped Prefetcher cannot hand a block out while an H2D is in flight
+                self.copy.wait_stream(torch.cuda.current_stream(self.device))
+                for d in dev:
+                    d.record_stream(self.copy)
                 self.slots[k] = (pin, dev)
             pin, dev = self.slots[k]
             if self.free[k] is not None:
@@ -235,6 +221,17 @@ class Prefetcher:
         ev.record(torch.cuda.current_stream(self.device))
         self.free[k] = ev
         self._fill()
+
+    def close(self):
+        """Leaving the loop early (--max_batches): wait for the copies still in flight before the slots are dropped."""
+        self.copy.synchronize()
+        self.queue.clear()
+
+    def __del__(self):
+        try:
+            self.copy.synchronize()
+        except Exception:
+            pass
 
 
 class DeviceMetrics:
@@ -356,6 +353,7 @@ def main(argv=None):
             losses.append(tr.train_step(xb, ycov, yb))
             pf.release()
             if args.max_batches and bi + 1 >= args.max_batches:
+                pf.close()
                 break
         tl = torch.stack(losses).mean()                               # one sync per epoch, not per step
         if world > 1:                                                 # the logged loss covers every rank's shard

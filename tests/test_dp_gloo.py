@@ -177,3 +177,75 @@ def test_flat_bucket_allreduce_and_grad_scale_world2():
     tot = O.clip_grad_norm(Gm, 5.0)
     flat = np.concatenate([(g0[o:o + P[k].size] * scale) for k, o in zip(PARAM_KEYS, offsets)])
     assert abs(np.sqrt((flat.astype(np.float64) ** 2).sum()) - tot) < 1e-5 * tot
+
+
+# ---- tile-table sharing and bench.py's launch plumbing (no GPU call anywhere) ----------------------------------------
+def _tune_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from megacrn_amd import dp, _lib
+    dp.init_from_env("gloo")
+    # ranks "tuned" differently: {kind 0 (tiled GEMM key, 9 words), cfg} and {kind 1 (bf16 GEMM key, 6 words), cfg}
+    mine = [0, 9, 1, 207, 4352, 207, 2, 1, 0, 1, 0, 3 + rank, 1, 6, 1, 7372, 1152, 1843, 1, 1, 4 + rank]
+    _lib.autotune_import(mine)
+    assert _lib.autotune_export() == mine
+    dp.share_autotune()
+    q.put((rank, _lib.autotune_export()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_adopt_rank0_tile_table_world2():
+    """dp.share_autotune: after independent tuning every replica runs rank 0's tiles (product code over gloo; the table
+    itself is host state of the library, no kernel runs)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tune_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and res[0][11] == 3 and res[0][-1] == 4
+
+
+def test_autotune_import_rejects_malformed_tables():
+    from megacrn_amd import _lib
+    for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 6] + [0] * 6 + [-1]):
+        with pytest.raises(RuntimeError):
+            _lib.autotune_import(bad)
+    _lib.autotune_import([])
+    assert _lib.autotune_export() == []
+
+
+def test_bench_self_launch_plumbing_gpus2(monkeypatch):
+    """`python bench.py --gpus 2` without a torchrun environment: the parent must only build the torchrun command line
+    (one rank per GPU, 127.0.0.1 rendezvous, its own arguments passed through) and hand it to a CHILD process - it must
+    not touch the GPU itself.  subprocess.call is mocked: nothing is launched."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                    # the children's exit code is passed on
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"     # dmabuf IPC: what RCCL needs on this pool

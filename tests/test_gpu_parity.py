@@ -502,6 +502,70 @@ def test_unchanged_trainer_statements_reproduce_reference_trajectory(amd):
     assert list(model.state_dict().keys()) == list(P.keys())
 
 
+def test_flat_trainer_two_layers_matches_reference_trajectory(amd):
+    """--num_rnn_layers 2 (model/traintest_MegaCRN.py:168 -> model/MegaCRN.py:71-78,109-112) through FlatTrainer: the
+    composed per-cell path under autograd with every .grad bound to the flat bucket, fused loss, fused clip + Adam,
+    against the reference's own 3-step loss trajectory of the 2-layer golden case."""
+    from megacrn_amd.trainer import FlatTrainer
+    rec, P, m = load_case("layers2", "f32")
+    assert m["num_layers"] == 2
+    model = build(amd, P, m).train()
+    flags = [[bool(v) for v in row] for row in rec["traj:teacher"]]
+    it = iter(flags)
+    model._teacher_flags = lambda labels, bs: next(it)
+    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+    x, ycov, y = dev(rec["x"]), dev(rec["ycov"]), dev(rec["labels"])
+    got = [tr.train_step(x, ycov, y).item() for _ in range(3)]
+    np.testing.assert_allclose(got, rec["traj:loss"], rtol=2e-4)
+    assert list(model.state_dict().keys()) == list(P.keys())
+    # gradients really live in the bucket (autograd accumulated in place), parameters are views of the flat buffer
+    for p_, g, o in zip(tr.params, tr.bucket.grad_views, tr.bucket.offsets):
+        assert p_.grad.data_ptr() == g.data_ptr() and p_.data_ptr() == tr.flat_p[o:o + 1].data_ptr()
+
+
+def test_expy_caller_clause_hooked_forward_and_inplace_reinit(amd):
+    """Row 8(b), second caller (model_EXPYTKY/traintest_MegaCRN.py:28-34): torchsummary-style forward hooks on every
+    sub-module with a B = 2 random input, then every parameter re-initialised IN PLACE by p.dim() - here after the
+    trainer has re-pointed the parameters at views of its flat bucket (dp.FlatBucket).  The re-initialised values must be
+    the ones the next train step uses, and the views must stay views."""
+    import torch.nn as nn
+    from megacrn_amd.trainer import FlatTrainer
+    N, T, H, M, D = 37, 3, 12, 5, 8
+    torch.manual_seed(3)
+    model = amd.MegaCRN(num_nodes=N, input_dim=1, output_dim=1, horizon=T, rnn_units=H, mem_num=M, mem_dim=D,
+                        use_curriculum_learning=False).cuda()
+    model.precision = amd.test_precision
+    seen = []
+    hooks = [mod.register_forward_hook(lambda mod, inp, out: seen.append(type(mod).__name__))
+             for mod in model.modules() if not isinstance(mod, (nn.Sequential, nn.ModuleList)) and mod is not model]
+    out = model(torch.rand(2, T, N, 1, device="cuda"), torch.rand(2, T, N, 1, device="cuda"))       # summary(): B = 2
+    for h in hooks:
+        h.remove()
+    assert tuple(out[0].shape) == (2, T, N, 1) and all(tuple(o.shape) == (2, N, D) for o in out[1:])
+    assert all(torch.isfinite(o).all() for o in out)
+    tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+    torch.manual_seed(4)
+    for p_ in model.parameters():                                                  # :30-34
+        if p_.dim() > 1:
+            nn.init.xavier_uniform_(p_)
+        else:
+            nn.init.uniform_(p_)
+    Pn = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    for p_, o in zip(tr.params, tr.bucket.offsets):                                # written THROUGH the views
+        assert p_.data_ptr() == tr.flat_p[o:o + 1].data_ptr()
+        assert torch.equal(tr.flat_p[o:o + p_.numel()], p_.detach().reshape(-1))
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, T, N, 1)).astype(np.float32)
+    ycov = rng.random((2, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((2, T, N, 1)).astype(np.float32)
+    loss = tr.train_step(dev(x), dev(ycov), dev(y)).item()
+    opt = O.Adam(Pn, lr=0.01, eps=1e-3)
+    want, _, _ = O.train_step(Pn, opt, x, ycov, y, [False] * T, SC_MEAN, SC_STD)
+    assert abs(loss - want[0]) < 2e-4 * abs(want[0])
+    for k, v in model.state_dict().items():                                        # and the Adam step landed on them
+        assert relerr(v.cpu().numpy(), Pn[k]) < 2e-4, k
+
+
 # ------------------------------------------------------------------------------------------------
 # every BASELINE.json config: reduced-batch train step vs the float64 oracle (N, H, M, D and therefore every kernel
 # variant of the production shape kept), plus size-independent properties at the FULL configuration
@@ -517,7 +581,10 @@ BASELINE_SHAPES = {
 }
 
 
-def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True, we_tol=TOL):
+WE_K = 4          # dWe1 / dWe2 at N >= 4096: at most WE_K x the oracle's own fp32-vs-fp64 distance on the same case
+
+
+def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True, we_tol=None):
     P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, seed=seed)
     rng = np.random.default_rng(seed + 1)
     for k in P:
@@ -555,9 +622,23 @@ def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True, we_tol=TOL):
     # supports of a large graph are nearly uniform, dS is nearly constant along each row, and the subtraction cancels
     # all but ~1/amp of it.  The reference's own fp32 arithmetic is then ~amp * 1e-7 away from float64 truth
     # (measured with the oracle: 2.4e-4 on dWe2 at N=1843, B=2, T=2), and a 1e-5 contraction ~amp * 1e-5.  At
-    # N >= 4096 these two gradients are therefore held to `we_tol`, everything else to 1e-4.
+    # N >= 4096 these two gradients are therefore held to WE_K x that measured fp32 noise (computed below on the same case),
+    # everything else to 1e-4.
+    # `we_tol` = None: everything at 1e-4.  "measured": the bound for dWe1 / dWe2 is k x the oracle's own fp32-vs-fp64
+    # distance on this very case (k = 4), i.e. the noise floor of the reference's own arithmetic, floored at 1e-4.
+    noise = {}
+    if we_tol == "measured":
+        P32 = {k: v.astype(np.float32) for k, v in P.items()}
+        o32, cache32 = O.model_fwd(P32, x, ycov, y, teacher)
+        G32, _ = O.model_bwd(d_out.astype(np.float32), cache32, d_query=d_q.astype(np.float32))
+        for k in ("memory.We1", "memory.We2"):
+            noise[k] = (relerr(G32[k], G[k]), relerr_rows(G32[k], G[k]))
+        print("oracle fp32-vs-fp64 noise on dWe1/dWe2:", noise)
+
     def lim(k):
-        return (we_tol, 10 * we_tol) if k in ("memory.We1", "memory.We2") else (TOL, ROW_TOL)
+        if k in noise:
+            return (max(TOL, WE_K * noise[k][0]), max(ROW_TOL, WE_K * noise[k][1]))
+        return (TOL, ROW_TOL)
     bad = {k: v for k, v in worst.items() if v[0] >= lim(k)[0] or v[1] >= lim(k)[1]}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])
     return worst
@@ -571,7 +652,7 @@ def test_baseline_config_train_step_vs_oracle(amd, name):
     N, T, H, M, D, B, Tr, _ = BASELINE_SHAPES[name]
     if name == "syn8192" and amd.test_precision == 0:
         pytest.skip("exact-fp32 MFMA at N=8192 is covered by the bf16x3 run of the same code path (validation mode only)")
-    _train_step_vs_oracle(amd, N, Tr, H, M, D, B, seed=21, we_tol=5e-2 if N >= 4096 else TOL)
+    _train_step_vs_oracle(amd, N, Tr, H, M, D, B, seed=21, we_tol="measured" if N >= 4096 else None)
 
 
 @pytest.mark.parametrize("name", ["pemsbay", "expytky", "syn8192"])
@@ -612,6 +693,7 @@ BF16_TOL = 2e-2        # stated tolerance of the mode (max-norm relative, like T
     (300, 3, 3, 12, 6, 8, 3),        # odd batch: plane rows padded to 8 channels; K tail of 300 = 4 x 64 + 44
     (261, 4, 2, 12, 6, 8, 2),        # cheb_k = 2: two stacked blocks, no T2
     (1843, 4, 6, 32, 10, 32, 3),     # EXPY-TKY geometry at a reduced batch
+    (8192, 2, 2, 64, 20, 64, 3),     # SYN-8192 geometry (the mode bench.py runs it in) at a reduced batch / sequence
 ])
 def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
     import megacrn_amd as amd
@@ -643,6 +725,112 @@ def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
     # same inputs, same workspace: bit-identical
     outs2 = model(dev(x), dev(ycov), dev(y), 0)
     assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+
+
+def _bf16_model(name, train):
+    import megacrn_amd as amd
+    amd.test_precision = amd._lib.BF16
+    N, T, H, M, D, _, _, B = BASELINE_SHAPES[name]
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, seed=4)
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=3, M=M, D=D, cl_decay=2000)
+    model = build(amd, P, m)
+    assert model.precision == amd._lib.BF16
+    return (model.train() if train else model.eval()), (N, T, B)
+
+
+@pytest.mark.parametrize("name", ["expytky", "syn8192"])
+def test_bf16_mode_full_size_properties(name):
+    """The large graphs in the arithmetic bench.py runs them in (bf16-resident propagation), at the FULL BASELINE batch and
+    sequence length: bit-identical re-run on the same workspace, batch-permutation equivariance, independence of the
+    other samples (prefix)."""
+    model, (N, T, B) = _bf16_model(name, train=False)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    perm = rng.permutation(B)
+    with torch.no_grad():
+        o1 = [t.clone() for t in model(dev(x), dev(ycov))]
+        o2 = model(dev(x), dev(ycov))
+        for a, b in zip(o1, o2):
+            assert torch.equal(a, b), "same inputs, same workspace -> bit-identical"
+        o3 = model(dev(x[perm]), dev(ycov[perm]))
+        # every sample's arithmetic is independent of its position and of its neighbours: only the tile a column falls
+        # into (hence the fp32 accumulation order) may differ
+        for a, b in zip(o1[:3], o3[:3]):
+            assert relerr(b.cpu().numpy(), a.cpu().numpy()[perm]) < 2e-5
+        half = model(dev(x[:B // 2]), dev(ycov[:B // 2]))
+        for a, b in zip(o1[:3], half[:3]):
+            assert relerr(b.cpu().numpy(), a.cpu().numpy()[:B // 2]) < 2e-5
+    assert all(torch.isfinite(t).all() for t in o1)
+
+
+ADD_TOL = {"bf16x3": 1e-4, "bf16": 1e-4}       # gradient additivity over half batches, per tensor (max-norm relative)
+
+
+@pytest.mark.parametrize("name,mode", [("pemsbay", "bf16x3"), ("expytky", "bf16x3"), ("expytky", "bf16"), ("syn8192", "bf16")])
+def test_full_batch_backward_is_sum_of_half_batches(name, mode):
+    """Backward at the FULL BASELINE batch (the oracle cannot run there in seconds): with a loss that is a fixed-weight
+    sum over samples (no batch-dependent normaliser), the gradient of the batch equals the sum of the gradients of its
+    two halves, for all 14 parameters.  Train mode with teacher forcing on alternating steps."""
+    import megacrn_amd as amd
+    amd.test_precision = amd._lib.PRECISIONS[mode]
+    N, T, H, M, D, _, _, B = BASELINE_SHAPES[name]
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, seed=6)
+    rng = np.random.default_rng(12)
+    for k in P:
+        if k.endswith("bias"):
+            P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=3, M=M, D=D, cl_decay=2000)
+    model = build(amd, P, m).train()
+    teacher = [bool(t % 2) for t in range(T)]
+    model._teacher_flags = lambda labels, bs: teacher
+    x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    w_out = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+    w_q = rng.standard_normal((B, N, D)).astype(np.float32)
+
+    def grads(lo, hi):
+        model.zero_grad(set_to_none=True)
+        out = model(dev(x[lo:hi]), dev(ycov[lo:hi]), dev(y[lo:hi]), 0)
+        ((out[0] * dev(w_out[lo:hi])).sum() + (out[2] * dev(w_q[lo:hi])).sum()).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.double().cpu().numpy() for k, p in model.named_parameters()}
+
+    full, a, b = grads(0, B), grads(0, B // 2), grads(B // 2, B)
+    errs = {k: relerr(a[k] + b[k], full[k]) for k in full}
+    print("additivity errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    assert all(np.isfinite(v).all() for v in full.values())
+    assert max(errs.values()) < ADD_TOL[mode], sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+
+
+def test_packed_fp32_erratum_reproducer_and_guard():
+    """DESIGN.md section 8 (packed-fp32 VALU instructions next to a foreign MFMA stream): the stand-alone harness
+    tools/kbench/wgrad_test runs the streaming weight-gradient kernel beside an MFMA-dense neighbour on another stream
+    and compares every slab bitwise with the solo run.  Built with the library's flags (-fno-slp-vectorize
+    -fno-vectorize) it must be bit-identical in every run; the same source with the SLP vectoriser on
+    (wgrad_test_slp: v_pk_mul_f32 in the mask multiplications) is the control that shows the harness still
+    provokes the problem - reported, not asserted: a fixed driver / microcode would make it pass too."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kb = os.path.join(root, "tools", "kbench")
+    exe, exe_slp = os.path.join(kb, "wgrad_test"), os.path.join(kb, "wgrad_test_slp")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17"]
+    if not os.path.exists(exe):
+        subprocess.run([hipcc] + flags + ["-fno-slp-vectorize", "-fno-vectorize", "-o", exe, os.path.join(kb, "wgrad_test.hip")],
+                       check=True, timeout=600)
+    env = dict(os.environ, MFMAN="1024", CONC="12", NROT="1")
+    for shape in ("1 80000 5 28 48 256", "1 80000 5 68 64 256"):
+        r = subprocess.run([exe] + shape.split() + ["2"], env=env, cwd=kb, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if "CONC:" in ln]
+        assert line and "CONC: 0 of 12 runs differ" in line[0], (shape, line, r.stdout[-1500:])
+    if os.path.exists(exe_slp):
+        r = subprocess.run([exe_slp] + "1 80000 5 28 48 256".split() + ["2"], env=env, cwd=kb, capture_output=True, text=True,
+                           timeout=300)
+        print("control (SLP on, packed fp32):", [ln.strip() for ln in r.stdout.splitlines() if "CONC:" in ln])
 
 
 # ------------------------------------------------------------------------------------------------

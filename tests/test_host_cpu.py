@@ -208,3 +208,119 @@ def test_shipped_kernels_use_no_packed_fp32_valu():
         assert nmfma > 1000          # we really looked at the kernels
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _device_code_objects(tmp):
+    """(path, disassembler) of every gfx950 code object inside the shipped library, or None when tools are absent."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "megacrn_amd", "libmegacrn_hip.so")
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    if not (os.path.exists(so) and os.path.exists(objcopy)):
+        return None
+    fat = os.path.join(tmp, "fatbin.bin")
+    subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", so, os.path.join(tmp, "copy.so")], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+    out = []
+    for n, i in enumerate(starts):
+        end = starts[n + 1] if n + 1 < len(starts) else len(data)
+        img = os.path.join(tmp, f"co{n}.elf")
+        open(img, "wb").write(data[i:end])
+        out.append(img)
+    return out
+
+
+def _vregs(operand_text):
+    """Set of VGPR numbers named in an operand string (v7, v[10:13])."""
+    import re
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", operand_text))
+    return regs
+
+
+def check_register_ring_contract(asm_lines):
+    """The WIDE fused propagation (prop_small.h: 256 < N <= 352) streams its adjacency fragments with inline-asm
+    `global_load_dwordx4 vDST, vOFF, s[base]` into a register ring and waits with hand-counted `s_waitcnt vmcnt(n)` in
+    separate asm statements.  That is only correct if (1) no instruction touches a ring destination while its load
+    is still outstanding - a register copy or spill in between would read data that has not landed - and (2) the counted
+    waits see exactly the VMEM operations the source assumes.  Replays the wave's vmcnt queue over the straight-line
+    instruction stream: every VMEM instruction enters the FIFO, `s_waitcnt vmcnt(n)` retires all but the youngest n.
+    Returns (number of ring loads checked, list of violations)."""
+    import re
+    fifo = []                      # outstanding VMEM ops, oldest first: set of destination VGPRs (empty for stores)
+    ring, bad = 0, []
+    for ln in asm_lines:
+        m = re.match(r"\s+(\S+)\s*(.*?)\s*//", ln)
+        if not m:
+            continue
+        op, args = m.group(1), m.group(2)
+        if op == "s_waitcnt":
+            c = re.search(r"vmcnt\((\d+)\)", args)
+            if c:
+                keep = int(c.group(1))
+                fifo = fifo[len(fifo) - keep:] if keep < len(fifo) else fifo
+            continue
+        touched = _vregs(args)
+        for dst in fifo:
+            if dst and dst & touched:
+                bad.append(ln.strip()[:90])
+                break
+        if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", op):
+            is_ring = op == "global_load_dwordx4" and re.search(r",\s*v\d+,\s*s\[\d+:\d+\]", args) is not None
+            dst = _vregs(args.split(",")[0]) if "_load" in op else set()
+            fifo.append(dst if is_ring else set())
+            ring += is_ring
+    return ring, bad
+
+
+def test_register_ring_checker_catches_an_early_read():
+    ok = ["\tglobal_load_dwordx4 v[4:7], v1, s[2:3]    // 0", "\tv_add_u32 v9, v8, v8    // 0", "\ts_waitcnt vmcnt(0)    // 0",
+          "\tv_mov_b32 v10, v4    // 0"]
+    assert check_register_ring_contract(ok) == (1, [])
+    early = [ok[0], "\tv_mov_b32 v10, v4    // 0", ok[2]]
+    assert len(check_register_ring_contract(early)[1]) == 1
+    counted = [ok[0], "\tglobal_load_dwordx4 v[12:15], v1, s[2:3] offset:1024    // 0", "\ts_waitcnt vmcnt(1)    // 0",
+               "\tv_mov_b32 v10, v5    // 0", "\tv_mov_b32 v11, v13    // 0"]
+    assert len(check_register_ring_contract(counted)[1]) == 1          # v13 belongs to the load still in flight
+
+
+def test_wide_fused_propagation_register_ring_contract():
+    """ADVICE (round 2): make the inline-asm register ring of prop2_{fwd,bwd}_kernel<9..11, 2> checkable on every build:
+    no scratch / VGPR spills in those kernels, and no instruction touches a ring register between its load and the
+    counted wait that retires it."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    tmp = tempfile.mkdtemp()
+    try:
+        cos = _device_code_objects(tmp)
+        if not cos or not (os.path.exists(objdump) and os.path.exists(readelf)):
+            pytest.skip("library or LLVM binutils not present")
+        want = [f"_ZN4mcrn16prop2_{d}_kernelILi{nf}ELi2EEEvNS_6Prop2PE" for d in ("fwd", "bwd") for nf in (9, 10, 11)]
+        seen = 0
+        for img in cos:
+            notes = subprocess.run([readelf, "--notes", img], capture_output=True, text=True, check=True).stdout
+            for sym in want:
+                if sym not in notes:
+                    continue
+                seen += 1
+                meta = notes[:notes.index(sym)]
+                meta = meta[meta.rindex("- .agpr_count") if "- .agpr_count" in meta else 0:] + notes[notes.index(sym):notes.index(sym) + 600]
+                priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta)
+                vsp = re.search(r"\.vgpr_spill_count:\s+(\d+)", meta)
+                assert priv and int(priv.group(1)) == 0, (sym, "scratch in a register-ring kernel")
+                assert vsp is None or int(vsp.group(1)) == 0, (sym, "VGPR spills in a register-ring kernel")
+                dis = subprocess.run([objdump, "-d", f"--disassemble-symbols={sym}", img], capture_output=True, text=True,
+                                     check=True).stdout.splitlines()
+                ring, bad = check_register_ring_contract(dis)
+                assert ring >= 20, (sym, ring)             # 2 loads per k-step, >= 18 k-steps per hop
+                assert not bad, (sym, bad[:5])
+        assert seen == len(want), f"only {seen} of {len(want)} wide propagation kernels found in the library"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

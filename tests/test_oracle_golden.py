@@ -104,3 +104,35 @@ def test_oracle_eval_metrics_match_reference_evaluate(golden_dir):
     assert abs(ep[0] - float(z["eval:mean_loss"])) < 1e-5 * abs(ep[0])
     logged = z["eval:logged"].reshape(-1)              # what the reference logs, 4 decimals
     np.testing.assert_allclose(np.array(ep[1:]), logged, atol=6e-5)
+
+
+# ---- the PyTorch-CPU restatement timed by bench.py's cpu_baseline leg (oracle/megacrn_torch_cpu.py) -------------------
+@pytest.mark.parametrize("name,dn", [("tiny", "f32"), ("odd", "f64"), ("layers2", "f32"), ("cheb2", "f64"), ("metrla", "f32")])
+def test_torch_cpu_restatement_matches_reference(name, dn):
+    """Same reference-generated vectors: eval forward, train-mode forward, loss, every gradient, grad norm, and the
+    3-step Adam trajectory (torch.optim.Adam(lr=0.01, eps=1e-3) + clip_grad_norm_(5), traintest_MegaCRN.py:104,129)."""
+    import torch
+    from oracle import megacrn_torch_cpu as TC
+    rec, Pn, m = load_case(name, dn)
+    dt = torch.float32 if dn == "f32" else torch.float64
+    t = lambda a: torch.tensor(np.asarray(a), dtype=dt)
+    torch.set_num_threads(4)
+    P = TC.make_params(Pn, dt)
+    x, ycov, y = t(rec["x"]), t(rec["ycov"]), t(rec["labels"])
+    with torch.no_grad():
+        outs = TC.forward(P, x, ycov, cheb_k=m["cheb_k"], num_layers=m["num_layers"])
+    for nm, o in zip(("output", "h_att", "query", "pos", "neg"), outs):
+        assert relerr(o.numpy(), rec["eval:" + nm]) < TOL[dn], nm
+    teacher = [bool(v) for v in rec["teacher"]]
+    outs = TC.forward(P, x, ycov, y, teacher, m["cheb_k"], m["num_layers"])
+    loss = TC.loss_terms(outs, y, SC_MEAN, SC_STD)
+    loss.backward()
+    assert abs(loss.item() - rec["train:loss"][0]) < 10 * TOL[dn] * abs(rec["train:loss"][0])
+    for k, p in P.items():
+        assert relerr(p.grad.numpy(), rec["g:" + k]) < GTOL[dn], k
+    if "traj:loss" in rec:
+        P = TC.make_params(Pn, dt)
+        opt = torch.optim.Adam(list(P.values()), lr=0.01, eps=1e-3)
+        got = [TC.train_step(P, opt, x, ycov, y, [bool(v) for v in rec["traj:teacher"][s]], SC_MEAN, SC_STD,
+                             m["cheb_k"], m["num_layers"]) for s in range(3)]
+        np.testing.assert_allclose(got, rec["traj:loss"], rtol=1e-4 if dn == "f32" else 1e-9)
