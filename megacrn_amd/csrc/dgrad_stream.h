@@ -23,7 +23,7 @@ namespace mcrn {
 
 // Wfrag[((j*KS + ks)*2 + hl)*64 + lane] = 8 bf16 (hi | lo) of W[n = 32 j + (lane&31)][k = 16 ks + 8 (lane>>5) + 0..7]
 // (W row-major [rows][ld], zero beyond rows / K)
-__global__ void k_wfrag_build(const float* __restrict__ W, long long ld, int rows, int K, int KS,
+static __global__ void k_wfrag_build(const float* __restrict__ W, long long ld, int rows, int K, int KS,
                               uint4* __restrict__ out, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -40,21 +40,6 @@ __global__ void k_wfrag_build(const float* __restrict__ W, long long ld, int row
     out[((long long)(j * KS + ks) * 2 + 0) * 64 + lane] = h;
     out[((long long)(j * KS + ks) * 2 + 1) * 64 + lane] = l;
 }
-static inline size_t wfrag_uint4(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * 64; }
-static inline bool dgrad_stream_ok(int O) { return O % 16 == 0 && O >= 16 && O <= 128; }
-
-struct DgradP {
-    const float* dY;        // [R][O]
-    const uint4* Wfrag;     // k_wfrag_build image of Wd [(g, c')][o]
-    float* dP;              // [G][R][Cp]  (plane stride PS)
-    unsigned short* dPb;    // MCRN_BF16: planes 1.. are written as bf16 here ([G-1][.][Cp] rows, plane stride PSb) and
-    long long PSb;          //   NOT to dP: they are only ever read as bf16 operands (S^T product, adjacency gradient)
-    long long R, PS;
-    int O, ncols, Cp;       // ncols = G*Cp
-    int ncf, parts, cf_per_part;
-    int dbg;                // -DMCRN_ABLATE builds only (MCRN_DEBUG bits): 1 = no stores, 2 = no MFMA, 4 = no B staging
-};
-
 template <int KS>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) void dgrad_stream_kernel(const DgradP p) {   // <= 3 waves per SIMD: keeps the compiler from spilling the staging registers to reach a higher occupancy
     constexpr int FRAG = KS * 2 * 64;                                 // uint4 per column fragment (hi and lo, all k-steps)

@@ -21,15 +21,14 @@
 #include <vector>
 
 #include "../../include/megacrn_hip.h"
-#include "gemm_f32.h"
-#include "gemm_bf16x3.h"
-#include "prop_small.h"
-#include "dgrad_stream.h"
+#include "kernels_api.h"
 #include "gemm_bf16_api.h"
 #include "wgrad_stream_api.h"
+#include "wp_stream_api.h"
 #include "ops.h"
 
 namespace mcrn {
+using namespace ext;   // host entry points of the kernel units (kernels_api.h)
 
 GemmStats g_gemm_stats = {0, 0.0};
 int g_force_cfg = -1;
@@ -283,6 +282,10 @@ struct Shp {   // one AGCN / cell geometry
     int B, N, d, H, C, Cp, K, G;
     long long R, ld, PS, ZT;   // rows, plane row stride (per node), plane size, plane-set size
     int Kp; long long ldp, PSb;   // MCRN_BF16: bf16 planes are [Kp = roundup(N, 64)][ldp = roundup(ld, 64)], zero padded
+    bool hoist; long long ldh;    // MCRN_BF16, H % 32 == 0: the per-step propagation covers the B*H state columns only (ldh);
+                                  // the input channels of every step are propagated once per stack
+    bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
+                                  // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
 };
 static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     Shp s;
@@ -296,6 +299,11 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.PS = s.R * s.Cp;
     s.ZT = s.PS * s.G;
     s.Kp = (N + 63) & ~63; s.ldp = (s.ld + 63) & ~63LL; s.PSb = (long long)s.Kp * s.ldp;
+    static const bool hoist_off = getenv("MCRN_HOIST") && atoi(getenv("MCRN_HOIST")) == 0;
+    s.hoist = bf16_rows && !hoist_off && (H % 32) == 0 && d > 0;
+    s.ldh = (long long)B * H;
+    static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
+    s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
 }
 
@@ -363,9 +371,10 @@ static std::map<Bf16Key, int> g_tuned_bf16;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
-    static const double eff[CFG_BF16_SK0] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8};
+    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8, 0, 0, 0, 0.85, 0.85, 0.85};
     int best = 0; double bt = 1e300;
-    for (int c = 0; c < CFG_BF16_SK0; ++c) {
+    for (int c = 0; c < NCFG_BF16; ++c) {
+        if (bf16_cfg_is_sk(c)) continue;
         const int per_cu = kCfgBf16[c][2];
         const long long tiles = (long long)cdiv(p.M, kCfgBf16[c][0]) * cdiv(p.N, kCfgBf16[c][1]) * nsplit;
         const double rounds = ceil((double)tiles / (256.0 * per_cu));
@@ -388,10 +397,11 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                 CK(hipEventCreate(&g_tune_ev[1]));
                 g_tune_ev_ok = true;
             }
-            float best_ms = 1e30f, cfg_ms[CFG_BF16_SK0];
-            for (int c = 0; c < CFG_BF16_SK0; ++c) cfg_ms[c] = 1e30f;
+            float best_ms = 1e30f, cfg_ms[NCFG_BF16];
+            for (int c = 0; c < NCFG_BF16; ++c) cfg_ms[c] = 1e30f;
             for (int round = 0; round < 3; ++round)              // min over 3 rounds of 5 launches: robust to clock / cache noise
-                for (int c = 0; c < CFG_BF16_SK0; ++c) {
+                for (int c = 0; c < NCFG_BF16; ++c) {
+                    if (bf16_cfg_is_sk(c)) continue;
                     CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));                   // warm-up
                     CK(hipEventRecord(g_tune_ev[0], st));
                     for (int r = 0; r < 5; ++r) CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));
@@ -401,12 +411,12 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                     CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
                     if (ms < cfg_ms[c]) cfg_ms[c] = ms;
                 }
-            for (int c = 0; c < CFG_BF16_SK0; ++c)
+            for (int c = 0; c < NCFG_BF16; ++c)
                 if (cfg_ms[c] < best_ms) { best_ms = cfg_ms[c]; cfg = c; }
             if (getenv("MCRN_TUNE_LOG")) {
                 fprintf(stderr, "[mcrn tune] bf16 %s role %d M=%d N=%d K=%dx%d split=%d:", btr ? "nn" : "nt", role, p.M, p.N, p.nseg,
                         p.seg_len, nsplit);
-                for (int c = 0; c < CFG_BF16_SK0; ++c) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
+                for (int c = 0; c < NCFG_BF16; ++c) if (!bf16_cfg_is_sk(c)) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
                 fprintf(stderr, " -> %d\n", cfg);
             }
             g_tuned_bf16[key] = cfg;
@@ -438,14 +448,57 @@ static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, ui
 // MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
 //   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
 // T2(S) = 2 S S - I is the reference's own matrix form (model/MegaCRN.py:20-22), built once per step.
-static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, uint16_t* x0c, hipStream_t st) {
-    CKI(plane_to_bf16(s, u, Z, x0b, x0c, st));
+static int pack_cols_bf16(const float* src, long long src_t, const Shp& s, int col0, int w, int T, int ldo, uint16_t* dst, hipStream_t st) {
+    const long long n = (long long)s.Kp * (ldo / 8);
+    LAUNCH(k_pack_cols_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, src, src_t, s.N, s.ld, s.Cp, col0, w, s.B, T, s.Kp, ldo,
+           reinterpret_cast<uint4*>(dst));
+    return 0;
+}
+static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, uint16_t* x0c, hipStream_t st,
+                         uint16_t* Pb = nullptr, bool packed = false) {
     Bf16GemmP p = bgp(u);
     p.A = u.Sstk; p.am = rm_plain(u.Kp); p.M = u.nb * s.N;
-    p.B = x0b; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = 1; p.seg_len = s.N; p.a_seg = 0; p.b_seg = 0;
     p.C = Z + s.PS; p.cm = rm_two(s.N, s.PS, s.ld);
+    if (s.lite && Pb) {
+        // bf16-resident planes: the product is written ONCE, as bf16 [nb][N][B*H]; its B operand x0b was emitted by the
+        // epilogue of the weight pool that produced the state (packed), or is packed here (first cell of a stack)
+        if (!packed) CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st));
+        p.B = x0b; p.ldb = s.ldh; p.N = (int)s.ldh;
+        p.C = nullptr; p.Cb = Pb; p.cbm = rm_plain(s.ldh);
+        return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.H, st);
+    }
+    if (s.hoist) {
+        // only the state channels change from step to step: B = their packed bf16 copy (N x B*H), the result lands in the
+        // h-channel block of every (node, sample) row of planes 1 .. nb; the input-channel blocks were filled by hoist_inputs
+        CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st));
+        p.B = x0b; p.ldb = s.ldh; p.N = (int)s.ldh;
+        p.cn_inner = s.H; p.cn_hi = s.Cp;
+        return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.H, st);
+    }
+    CKI(plane_to_bf16(s, u, Z, x0b, x0c, st));
+    p.B = x0b; p.ldb = s.ldp; p.N = (int)s.ld;
     return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+}
+// MCRN_BF16, hoisted input channels: columns [col0, col0 + w) of plane 0 of the T plane sets Z[t] (stride s.ZT) are
+// propagated in ONE product  [S1; T2(S1); S2; T2(S2)] x [N x T*B*w]  and written to the same columns of planes 1 .. nb of
+// Z[t] and Y[t] (gate and candidate input share their input channels, model/MegaCRN.py:42,45).
+static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, uint16_t* xin_b, float* xin_t,
+                        hipStream_t st) {
+    if (!s.hoist || w <= 0 || T <= 0) return 0;
+    const int ncols = T * s.B * w;
+    const int ncp = ncols < 8 ? 8 : (ncols + 7) & ~7;
+    CKI(pack_cols_bf16(Z, s.ZT, s, col0, w, T, ncp, xin_b, st));
+    Bf16GemmP p = bgp(u);
+    p.A = u.Sstk; p.am = rm_plain(u.Kp); p.M = u.nb * s.N;
+    p.B = xin_b; p.ldb = ncp; p.N = ncp;
+    p.nseg = 1; p.seg_len = s.N;
+    p.C = xin_t; p.cm = rm_plain(ncp);
+    CKI(bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));
+    const long long tot = (long long)u.nb * s.N * ncols;
+    LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, u.nb, s.N, s.B, w, T, Z, Y, s.ZT, s.PS,
+           s.ld, s.Cp, col0);
+    return 0;
 }
 // MCRN_BF16 backward propagation: dP[0] += [S1^T | T2(S1)^T | S2^T | T2(S2)^T] x [dP[1]; ..; dP[nb]]  (K = nb*N)
 // The output is only N x B*Cp (135 / 255 tiles of 128 x 128 at EXPY-TKY) while K is nb*N deep: K is split in two, the
@@ -459,7 +512,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
     int nsplit = 1;
     static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 2;
-    if (dT && used_dT && split_env == 2 && g_force_cfg_bf16 < CFG_BF16_SK0 && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
+    if (dT && used_dT && split_env == 2 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
         nsplit = 2; p.slab = dT - dP; p.cin_first_only = 1;
         *used_dT = true;
     }
@@ -479,8 +532,9 @@ static int ds_bf16(const Shp& s, const Sup& u, const uint16_t* dPb_all, const ui
 }
 
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
-static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr) {
-    if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st);
+static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr,
+                    uint16_t* Pb = nullptr, bool packed = false) {
+    if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st, Pb, packed);
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
@@ -727,12 +781,17 @@ static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* d
            ((step_stride | s.PS) & 3) == 0;
 }
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
-                      int O, float* slabs, hipStream_t st, int* nslab, bool* ones = nullptr) {
+                      int O, float* slabs, hipStream_t st, int* nslab, bool* ones = nullptr,
+                      const uint16_t* Xb = nullptr /* bf16-resident planes of these calls */, long long xb_step = 0, long long xb_plane = 0) {
     // ones != null: the caller wants the column sums of dY (bias gradient) as row G*Cp of the slabs when the streaming
     // kernel runs (*ones = true), and computes them itself otherwise
     if (ones) *ones = false;
-    if (wgrad_streams(s, O, Xall, dYall, step_stride, T)) {
+    const bool streams = wgrad_streams(s, O, Xall, dYall, step_stride, T);
+    if (Xb && !streams) FAIL("weight gradient: bf16-resident planes need the streaming kernel (shape / alignment / MCRN_WGRAD_STREAM)");
+    if (streams) {
         WgradP q;
+        memset(&q, 0, sizeof q);
+        q.Xb = Xb; q.xb_step = xb_step; q.xb_plane = xb_plane; q.H = s.H;
         q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
         q.dY = dYall; q.O = O; q.slabs = slabs; q.ones = ones ? 1 : 0;
         if (ones) *ones = true;
@@ -794,12 +853,45 @@ static int centre_planes(const Shp& s, const Sup& u, const float* Zall, const fl
 }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
-struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr; };
+struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr;
+               const uint4 *wp_g = nullptr, *wp_u = nullptr; /* weight images of the streaming weight pool (wp_stream.h) */ };
+// streaming weight pool on bf16-resident planes (wp_stream.h) with the library's profiling hooks
+static int wp_stream(const Shp& s, const Sup& u, const float* Z, const uint16_t* Pb, const uint4* img, const float* bias, int epi,
+                     float* out, float* out2, long long out2_ld, uint16_t* out2b, const float* hsrc, long long hsrc_ld,
+                     const float* zr, hipStream_t st) {
+    WpP q;
+    memset(&q, 0, sizeof q);
+    q.Z = Z; q.Pb = Pb; q.PS = s.PS; q.PSh = s.R * s.H; q.R = s.R; q.Cp = s.Cp; q.H = s.H; q.d = s.d; q.nbp = u.nb;
+    q.O = epi == WP_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
+    q.out = out; q.out2 = out2; q.out2_ld = out2_ld; q.out2b = out2b; q.hsrc = hsrc; q.hsrc_ld = hsrc_ld; q.zr = zr;
+    const double alg = 2.0 * (double)s.R * (2.0 * s.K * s.C) * q.O;
+    MCRN_PROF_WRAP(ROLE_WP, launch_wp_stream(q, st), 2.0 * (double)s.R * ((double)s.G * s.H + 16.0) * q.O, alg);
+    return 0;
+}
 
 // x0b / x0c: bf16 slots of this cell's two AGCN calls (gate first, update second), or nullptr
 static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* zr, float* hc,
                          const CellW& w, float* hnext, long long hnext_ld, hipStream_t st, uint16_t* x0b = nullptr,
-                         uint16_t* x0c = nullptr) {
+                         uint16_t* x0c = nullptr, uint16_t* Pb = nullptr /* this cell's bf16 planes: gate call, update call */,
+                         bool packed = false /* x0b of the gate call was emitted by the previous cell's epilogue */,
+                         uint16_t* x0b_next = nullptr /* where this cell's new state goes as the next gate call's operand */) {
+    if (g_prop_bf16 && s.lite && Pb && x0b && w.wp_g && w.wp_u) {
+        const long long PbS = (long long)u.nb * s.N * s.ldh;
+        CKI(prop_fwd(s, u, Z, st, x0b, x0c, Pb, packed));
+        CKI(wp_stream(s, u, Z, Pb, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, x0b + s.PSb, nullptr, 0, nullptr, st));
+        CKI(prop_fwd(s, u, Y, st, x0b + s.PSb, x0c ? x0c + s.PSb : nullptr, Pb + PbS, true));
+        CKI(wp_stream(s, u, Y, Pb + PbS, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, x0b_next, Z, s.Cp, zr, st));
+        return 0;
+    }
+    static const int wp_dbg = getenv("MCRN_WP_DBG") ? atoi(getenv("MCRN_WP_DBG")) : 3;   // debugging: bit 0 = H <= 64 cells, bit 1 = H > 64 cells
+    if (w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && aligned16(Z) && aligned16(Y) && (wp_dbg & (s.H <= 64 ? 1 : 2))) {
+        // streaming weight pool on fp32 planes (bf16x3 arithmetic: the 1e-4 parity mode of the small graphs)
+        CKI(prop_fwd(s, u, Z, st, x0b, x0c));
+        CKI(wp_stream(s, u, Z, nullptr, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, nullptr, nullptr, 0, nullptr, st));
+        CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PSb : nullptr, x0c ? x0c + s.PSb : nullptr));
+        CKI(wp_stream(s, u, Y, nullptr, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, nullptr, Z, s.Cp, zr, st));
+        return 0;
+    }
     CKI(prop_fwd(s, u, Z, st, x0b, x0c));
     GemmP e = gp();
     e.epi = EPI_GATE; e.C[0] = zr; e.bias = w.bg; e.hsrc = Z; e.hsrc_ld = s.Cp;
@@ -923,9 +1015,7 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
         if (o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
             const float* src[4] = {g1, g2, o.St1, o.St2};
             const long long lds_[4] = {ldg, ldg, o.ldS, o.ldS};
-            const long long n = (long long)((N + 31) / 32) * 4 * o.simg_n;
-            for (int i = 0; i < 4; ++i)
-                LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, src[i], 1LL, lds_[i], N, N, o.simg_n, 1, o.simg[i]);
+            for (int i = 0; i < 4; ++i) { ++g_launches; CK(launch_bimg_build(src[i], 1LL, lds_[i], N, N, o.simg_n, 1, o.simg[i], st)); }
         }
     }
     return 0;
@@ -1004,17 +1094,15 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
         const int Kp = s.G * s.Cp;
         {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
             const int npad = (O + 3) & ~3;
-            const long long n = (long long)((Kp + 31) / 32) * 4 * npad;
-            LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wf, (long long)O, 1LL, Kp, O, npad, 0, imgf);
+            ++g_launches; CK(launch_bimg_build((const float*)Wf, (long long)O, 1LL, Kp, O, npad, 0, imgf, st));
         }
         if (dgrad_stream_ok(O)) {   // d-grad, streaming kernel: Wd [(g,c')][o] in MFMA B-fragment order
             const int KS = O / 16;
             const long long tot = (long long)((Kp + 31) / 32) * KS * 64;
-            LAUNCH(k_wfrag_build, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)Wd, (long long)O, Kp, O, KS, imgd, tot);
+            ++g_launches; CK(launch_wfrag_build((const float*)Wd, (long long)O, Kp, O, KS, imgd, tot, st));
         } else {   // d-grad, tiled GEMM: B[k = o][n = k'] = Wd[k'*O + o]
             const int npad = (Kp + 3) & ~3;
-            const long long n = (long long)((O + 31) / 32) * 4 * npad;
-            LAUNCH(k_bimg_build, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)Wd, 1LL, (long long)O, O, Kp, npad, 1, imgd);
+            ++g_launches; CK(launch_bimg_build((const float*)Wd, 1LL, (long long)O, O, Kp, npad, 1, imgd, st));
         }
     }
     return 0;
@@ -1059,6 +1147,9 @@ struct ModelPlan {
     uint16_t *Sstk, *STstk, *sqb;   // sqb: one zero-padded bf16 [Kp][Kp] matrix (S for the T2 product, dT in the backward pass)
     float *T2[2], *dA, *mu, *mu_part;
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
+    uint16_t* xin_b; float* xin_t;   // hoisted input channels: packed bf16 operand [Kp][ncp] and its fp32 product [nb*N][ncp]
+    uint16_t *Pb_e, *Pb_d;           // bf16-resident propagated planes of every AGCN call: [T][gate, update][nb][N][B*H]
+    uint4* wpimg[4];                 // weight images of the streaming weight pool (enc gate, enc update, dec gate, dec update)
     size_t total;
 };
 
@@ -1147,7 +1238,20 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.nb = 2 * (K - 1); P.Kp = (N + 63) & ~63;
     P.Sstk = P.STstk = P.sqb = nullptr; P.T2[0] = P.T2[1] = P.dA = P.mu = P.mu_part = nullptr;
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
+    P.xin_b = nullptr; P.xin_t = nullptr;
+    P.Pb_e = P.Pb_d = nullptr;
+    for (int i = 0; i < 4; ++i) P.wpimg[i] = nullptr;
     if (P.bf16) {
+        if (P.se.lite && P.sd.lite) {
+            P.Pb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * N * P.se.ldh + 64);     // (+ slack: 16-byte reads of 8-byte quads)
+            P.Pb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * N * P.sd.ldh + 64);
+        }
+        {
+            const long long ce = (long long)d->T_in * B * d->input_dim, cd = (long long)d->T_out * B * (od + yd);
+            const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 7) & ~7LL) + 8;
+            P.xin_b = b.take<uint16_t>((size_t)P.Kp * ncp);
+            P.xin_t = b.take<float>((size_t)P.nb * N * ncp);
+        }
         P.Sstk = b.take<uint16_t>((size_t)P.nb * N * P.Kp);
         P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
         P.sqb = b.take<uint16_t>((size_t)P.Kp * P.Kp);
@@ -1162,6 +1266,14 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
         P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PSb);
         P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PSb);
+    }
+    {
+        // streaming weight pool (wp_stream.h): bf16x3 sessions (fp32 planes) and the bf16 mode (bf16-resident planes when lite)
+        static const bool wp_off = getenv("MCRN_WP_STREAM") && atoi(getenv("MCRN_WP_STREAM")) == 0;
+        const bool ok = !wp_off && d->precision != MCRN_F32 && wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(H, d->input_dim, P.nb, 2 * H) &&
+                        wp_stream_ok(Hd, od + yd, P.nb, Hd) && wp_stream_ok(Hd, od + yd, P.nb, 2 * Hd);
+        if (ok)
+            for (int i = 0; i < 4; ++i) P.wpimg[i] = b.take<uint4>(wp_img_uint4(i < 2 ? H : Hd, P.nb, Os[i]));
     }
     P.total = (b.off + 255) & ~(size_t)255;
 }
@@ -1358,6 +1470,25 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const float* Wsrc[4] = {p->enc_gate_w, p->enc_update_w, p->dec_gate_w, p->dec_update_w};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], ps, P.imgf[i], P.imgd[i]));
+    const bool lite = P.bf16 && P.Pb_e != nullptr;
+    if (lite && P.Kp > N) {
+        // the propagation operands [Kp][B*H] that the weight-pool epilogues emit cover the N data rows only: their pad
+        // rows must be finite (gemm_bf16.h contract: they meet the zero K-padding of the stacked adjacency)
+        for (int e_ = 0; e_ < 2; ++e_) {
+            const Shp& s_ = e_ ? sd : se;
+            const long long np_ = (long long)2 * (e_ ? To : Ti), per = (long long)(s_.Kp - N) * (s_.ldh / 8);
+            LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, ps, reinterpret_cast<uint4*>(e_ ? P.x0b_d : P.x0b_e),
+                   s_.PSb / 8, N, s_.Kp, (int)(s_.ldh / 8), np_);
+        }
+    }
+    const bool wps = P.wpimg[0] != nullptr;
+    if (lite && !wps) FAIL("bf16-resident planes need the streaming weight pool (MCRN_WP_STREAM=0 with MCRN_BF16_PLANES on)");
+    if (wps)
+        for (int i = 0; i < 4; ++i) {
+            const Shp& sh_ = i < 2 ? se : sd;
+            ++g_launches;
+            CK(launch_wp_img_build(P.Wf[i], sh_.Cp, sh_.H, sh_.d, P.nb, Os[i], sh_.R, P.wpimg[i], ps));
+        }
     // decoder input columns (:181-183): covariates, zero pad columns, go symbol = 0; the state columns of Zdec[0] are
     // written by the memory head after the encoder
     if (yd > 0) {
@@ -1368,6 +1499,18 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
     CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));   // go = 0 (:182)
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));
+    if (sd.hoist && To > 1) {
+        // the go symbol of step t+1 is labels[:, t] wherever step t is teacher-forced (:188-191): known now, so it takes
+        // part in the hoisted propagation of the decoder's input channels; the other steps' go columns are zero until
+        // their projection writes them (their planes are then propagated per step, below)
+        if (labels) {
+            CKI(fill_cols(P.Zdec + sd.ZT, sd.ZT, sd.Cp, Hd, od, labels, (long long)To * N * od, (long long)N * od, od, B, N, To - 1, ps));
+            CKI(fill_cols(P.Ydec + sd.ZT, sd.ZT, sd.Cp, Hd, od, labels, (long long)To * N * od, (long long)N * od, od, B, N, To - 1, ps));
+        } else {
+            CKI(zero_cols(P.Zdec + sd.ZT, sd.ZT, sd.Cp, Hd, Hd + od, R, To - 1, ps));
+            CKI(zero_cols(P.Ydec + sd.ZT, sd.ZT, sd.Cp, Hd, Hd + od, R, To - 1, ps));
+        }
+    }
     CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
     Sup u = model_sup(P, N);
     if (P.bf16) CKI(build_stacks(P, u, N, d->cheb_k, st));
@@ -1381,27 +1524,40 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
         CK(hipEventRecord(g_side.join, g_side.st));
         CK(hipStreamWaitEvent(st, g_side.join, 0));
     }
+    if (P.bf16) {   // t-invariant part of the propagation: the input channels of every step, once per stack
+        CKI(hoist_inputs(se, u, P.Zenc, P.Yenc, Ti, H, din, P.xin_b, P.xin_t, st));
+        CKI(hoist_inputs(sd, u, P.Zdec, P.Ydec, To, Hd, od + yd, P.xin_b, P.xin_t, st));
+    }
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
+    if (wps) { we.wp_g = P.wpimg[0]; we.wp_u = P.wpimg[1]; }
+    const long long PbS_e = (long long)P.nb * N * se.ldh, PbS_d = (long long)P.nb * N * sd.ldh;
     for (int t = 0; t < Ti; ++t)
         CKI(cell_fwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
                           we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PSb : nullptr,
-                          P.bf16 ? P.x0c_e + (long long)2 * t * se.PSb : nullptr));
+                          P.bf16 ? P.x0c_e + (long long)2 * t * se.PSb : nullptr,
+                          lite ? P.Pb_e + (long long)2 * t * PbS_e : nullptr, t > 0,
+                          lite && t + 1 < Ti ? P.x0b_e + (long long)2 * (t + 1) * se.PSb : nullptr));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
                           P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
     // ---- decoder (:181-192): its input columns were packed at the top of the step
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
+    if (wps) { wd.wp_g = P.wpimg[2]; wd.wp_u = P.wpimg[3]; }
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
         CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
                           P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PSb : nullptr,
-                          P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr));
+                          P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr,
+                          lite ? P.Pb_d + (long long)2 * t * PbS_d : nullptr, t > 0,
+                          lite && t + 1 < To ? P.x0b_d + (long long)2 * (t + 1) * sd.PSb : nullptr));
         const bool last = t + 1 == To;
         const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;
         LAUNCH(k_proj_fwd, dim3(cdiv(R, 4) < 2048 ? cdiv(R, 4) : 2048), dim3(256), 0, st, (const float*)Zn,
                (long long)sd.Cp, p->proj_w, p->proj_b, Hd, od, B, N, output + (long long)t * N * od,
                (long long)To * N * od, (long long)od, last ? (float*)nullptr : Zn,
                last ? (float*)nullptr : P.Ydec + (t + 1) * sd.ZT, (long long)sd.Cp, Hd, lab);
+        // go = proj(h') was not known when the decoder's input channels were hoisted: propagate this one channel block now
+        if (P.bf16 && !last && !lab) CKI(hoist_inputs(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_b, P.xin_t, st));
     }
     return 0;
 }
@@ -1506,9 +1662,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     }
     int ns1 = 0;
     bool on1 = false, on2 = false, on3 = false, on4 = false;
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1));
+    const bool lite = P.bf16 && P.Pb_e != nullptr;
+    const long long PbS_e = (long long)P.nb * N * se.ldh, PbS_d = (long long)P.nb * N * sd.ldh;
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
     int ns2 = 0;
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
     CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1, on1 ? g->dec_gate_b : nullptr));
     CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2, on2 ? g->dec_update_b : nullptr));
     if (!on1) CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
@@ -1540,9 +1698,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         }
     }
     int ns3 = 0;
-    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3, &on3));
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
     int ns4 = 0;
-    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4, &on4));
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4, &on4, lite ? P.Pb_e + PbS_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
     CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st, ns3, on3 ? g->enc_gate_b : nullptr));
     CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st, ns4, on4 ? g->enc_update_b : nullptr));
     if (!on3) CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
@@ -1680,8 +1838,7 @@ int mcrn_set_debug(int bits) { g_debug = bits; return 0; }
 #ifdef MCRN_TIMELINE
 // measurement-only builds: copy out the in-kernel phase stamps (prop_small.h)
 int mcrn_debug_timeline(void* host_out, size_t bytes) {
-    CK(hipDeviceSynchronize());
-    CK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tl), bytes < sizeof(g_tl) ? bytes : sizeof(g_tl)));
+    CK(timeline_copy(host_out, bytes));
     return 0;
 }
 #endif

@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "gemm_bf16_api.h"
 
 namespace mcrn {
@@ -188,6 +189,39 @@ __device__ __forceinline__ bf16x8_t bf16_read_b(const unsigned char* sB, int bof
 // first row) + a 32-bit lane offset, and fragments that lie completely inside the matrix - wave-uniform test - store
 // unpredicated.  (The first version evaluated a two-level row map with an integer division per element and a bounds
 // branch per store: ~6000 instructions, 15-25 % of a K = 1843 launch.)
+// bf16-only output (C == null, Cb != null: the bf16-resident planes of the propagation) through LDS: the C/D layout gives a
+// lane ONE column of 16 rows, i.e. 2-byte stores; staged in the wave's private LDS region (rows of 128 bytes, the 64-byte
+// halves of rows 4..7 (mod 8) swapped so that the two lane halves of a ds_write_b16 hit different banks) every lane
+// then stores 16 contiguous bytes: 8 x fewer store instructions, full 128-byte lines.  Only whole-tile fragments, FN == 2.
+template <int FM, int FN>
+__device__ __forceinline__ bool bf16_epilogue_wide(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int r_base, int c_base, int lane,
+                                                   unsigned char* wave_lds) {
+    if (FN != 2) return false;
+    const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
+    if (rw + 32 * FM > p.M || cw + 64 > p.N) return false;                 // wave-uniform
+    const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 32 * i + 4 * kq + (v & 3) + 8 * (v >> 2);
+                unsigned u = __float_as_uint(p.alpha * acc[i][j][v]);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                *reinterpret_cast<uint16_t*>(wave_lds + row * 128 + ((64 * j + 2 * l31) ^ (kq << 6))) = (uint16_t)(u >> 16);   // ((row >> 2) & 1) == kq
+            }
+    const int ldb = (int)p.cbm.lo;
+    uint16_t* __restrict__ dst = p.Cb + (long long)rw * ldb + cw;
+#pragma unroll
+    for (int n = 0; n < 4 * FM; ++n) {
+        const int q = lane + 64 * n, row = q >> 3, c = q & 7;
+        const uint4 val = *reinterpret_cast<const uint4*>(wave_lds + row * 128 + ((16 * c) ^ (((row >> 2) & 1) << 6)));
+        *reinterpret_cast<uint4*>(dst + (long long)row * ldb + 8 * c) = val;
+    }
+    return true;
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int split, int r_base, int c_base,
                                               int lane) {
@@ -197,11 +231,19 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
     const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
     const bool cols_in = cw + 32 * FN <= p.N;
+    // column offset of fragment j (scalar): contiguous columns, or the two-level map of cn_inner / cn_hi - a 32-column
+    // fragment never straddles an inner block (cn_inner % 32 == 0, fragments start at multiples of 32)
+    int cof[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int cj = cw + 32 * j;
+        cof[j] = p.cn_inner > 0 ? (cj / p.cn_inner) * p.cn_hi + (cj - (cj / p.cn_inner) * p.cn_inner) : cj;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int rb = rw + 32 * i;                                  // first row of the fragment (scalar)
         if (rb >= p.M) break;
-        const long long base = (long long)rb * ld + cw;
+        const long long base = (long long)rb * ld;
         const unsigned lo0 = (unsigned)(4 * kq * ld + l31);
         float* __restrict__ Cf = C ? C + base : nullptr;
         const float* __restrict__ Cif = Cin ? Cin + base : nullptr;
@@ -215,11 +257,11 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
                 for (int v = 0; v < 16; ++v) x[v] = p.alpha * acc[i][j][v];
                 if (Cif) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) x[v] += p.beta * Cif[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + 32 * j];
+                    for (int v = 0; v < 16; ++v) x[v] += p.beta * Cif[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + cof[j]];
                 }
                 if (Cf) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) Cf[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + 32 * j] = x[v];
+                    for (int v = 0; v < 16; ++v) Cf[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + cof[j]] = x[v];
                 }
                 if (Cbf) {
 #pragma unroll
@@ -237,7 +279,7 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
                 for (int v = 0; v < 16; ++v) {
                     const int dr = (v & 3) + 8 * (v >> 2);
                     if (rb + 4 * kq + dr < p.M && cw + 32 * j + l31 < p.N) {
-                        const unsigned o = lo0 + (unsigned)(dr * ld) + 32 * j;
+                        const unsigned o = lo0 + (unsigned)(dr * ld) + cof[j];
                         float x = p.alpha * acc[i][j][v];
                         if (Cif) x += p.beta * Cif[o];
                         if (Cf) Cf[o] = x;
@@ -326,6 +368,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
             tl.issue(lds_base, wr, wave);                        // refill the stage tile t-1 left (all waves passed the barrier)
         }
         if (++rd == NSTAGE) rd = 0;
+    }
+    if (p.wide_cb && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
+        __syncthreads();                                         // every wave is done reading the operand stages
+        if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128))) return;
     }
     bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
@@ -447,6 +493,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[L::FM][L::FN];
     L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
+    if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
+        __syncthreads();                                         // both groups: every fragment read of the K loop has retired
+        if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128))) return;
+    }
     bf16_epilogue<L::FM, L::FN>(p, acc, split, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
 }
 
@@ -683,7 +733,13 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
         case 9: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
         case 10: return launch_one_bf16_sk<256, 256, 64, 2, BTR, ROLE>(p, st);             // 128 KB   1   stream-K
         case 11: return launch_one_bf16_sk<256, 128, 64, 2, BTR, ROLE>(p, st);             //  96 KB   1   stream-K
-        default: return launch_one_bf16_sk<192, 256, 64, 2, BTR, ROLE>(p, st);             // 112 KB   1   stream-K
+        case 12: return launch_one_bf16_sk<192, 256, 64, 2, BTR, ROLE>(p, st);             // 112 KB   1   stream-K
+        // FOUR waves (one per SIMD), 128 x 64 wave tiles: a 32K-output tile - the size that fills 256 CUs in one round on
+        // the hoisted N = 1843 encoder product (7372 x 1024: 232 tiles) - read with 0.75 LDS fragment reads per MFMA, like
+        // the 256 x 256 eight-wave tile (the eight-wave 256 x 128 forms have 64 x 64 or 128 x 32 wave tiles: 1.0 / 1.25)
+        case 13: return launch_one_bf16<256, 128, 2, 2, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
+        case 14: return launch_one_bf16<128, 256, 1, 4, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
+        default: return launch_one_bf16<256, 192, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);  // 112 KB   1   128 x 96 wave tiles
     }
 }
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {
@@ -693,6 +749,12 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
     if (p.cbm.inner > 0 && p.cbm.hi == (long long)p.cbm.inner * p.cbm.lo) p.cbm = rm_plain(p.cbm.lo);
     if (p.cm.inner > 0 || (p.Cb && p.cbm.inner > 0)) return hipErrorInvalidValue;   // the epilogue addresses plain-strided rows
     if (btr && ((p.N & 7) || p.N < 8)) return hipErrorInvalidValue;     // [k][n] operands are fetched in 8-column chunks
+    if (p.cn_inner > 0 && ((p.cn_inner & 31) || p.Cb)) return hipErrorInvalidValue;   // a fragment must not straddle an inner block
+    {
+        static const bool wide_off = getenv("MCRN_BF16_WIDE_EPI") && atoi(getenv("MCRN_BF16_WIDE_EPI")) == 0;
+        p.wide_cb = (!wide_off && p.Cb && !p.C && !p.Cin && p.nsplit <= 1 && nsplit <= 1 && (p.cbm.lo & 7) == 0 &&
+                     ((uintptr_t)p.Cb & 15) == 0) ? 1 : 0;
+    }
     // each hot role uses one storage form of B; everything else is "misc"
     if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
     if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);

@@ -32,13 +32,16 @@ struct Bf16GemmP {
     float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
     const float* Cin;         // nullable
     int cin_first_only;       // split-K: only split 0 adds Cin (the other splits write plain partial results)
-    RowMap cm;                // C row m -> element offset, columns contiguous
+    RowMap cm;                // C row m -> element offset, columns contiguous unless cn_inner > 0
+    int cn_inner;             // > 0: column j of C sits at (j / cn_inner) * cn_hi + j % cn_inner (cn_inner % 32 == 0): the
+    int cn_hi;                //      h-channel block of every (node, sample) row of a plane set [n][b][Cp]; applies to C, Cin
     float alpha, beta;
     int nsplit, tiles_per_split;   // split-K over k-tiles ; C / Cin of split z at + z * slab
     long long slab;
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
     int xcd;                  // 1: XCD-aware tile order
+    int wide_cb;              // set by the launcher: bf16-only output staged through LDS into 16-byte stores
     // stream-K configurations only (launch_gemm_bf16 fills them from the per-stream workspace it owns)
     float* sk_ws;             // one BM x BN fp32 partial tile per workgroup
     int* sk_flag;             // one word per workgroup: epoch of the partial it last published
@@ -47,15 +50,17 @@ struct Bf16GemmP {
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st);
-static const int NCFG_BF16 = 13;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
+static const int NCFG_BF16 = 16;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
 static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
                                            {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1},
-                                           {256, 256, 1}, {256, 128, 1}, {192, 256, 1}};
-// Configurations >= CFG_BF16_SK0 are stream-K (one output, nsplit ignored).  They are NOT in the tuner's candidate set:
-// measured (profiles/r2/kbench_streamk.txt) they only tie the best ping-pong configuration on the N = 1843 products -
-// the fp32 partial tiles have to cross XCDs through the memory side (256 KB written + read per workgroup, ~25 us of a
-// ~55 us ideal) - so they stay an opt-in (MCRN_BF16_CFG=10..12) and a harness case.
-static const int CFG_BF16_SK0 = 10;
+                                           {256, 256, 1}, {256, 128, 1}, {192, 256, 1},
+                                           {256, 128, 1}, {128, 256, 1}, {256, 192, 1}};
+// Configurations CFG_BF16_SK0 .. CFG_BF16_SK1 - 1 are stream-K (one output, nsplit ignored).  They are NOT in the tuner's
+// candidate set: measured (profiles/r2/kbench_streamk.txt) they only tie the best ping-pong configuration on the N = 1843
+// products - the fp32 partial tiles have to cross XCDs through the memory side (256 KB written + read per workgroup, ~25 us
+// of a ~55 us ideal) - so they stay an opt-in (MCRN_BF16_CFG=10..12) and a harness case.
+static const int CFG_BF16_SK0 = 10, CFG_BF16_SK1 = 13;
+static inline bool bf16_cfg_is_sk(int c) { return c >= CFG_BF16_SK0 && c < CFG_BF16_SK1; }
 // frees the stream-K workspaces (library teardown / tests)
 void bf16_gemm_release_workspaces();
 

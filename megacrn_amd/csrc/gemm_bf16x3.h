@@ -44,7 +44,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
 
 // Pre-split image of a static B operand (weights): built once per step, consumed by every tile load of every
 // launch that uses it.  element(k, n) = src[k*sk + n*sn]; k >= K or n >= N -> 0.
-__global__ void k_bimg_build(const float* __restrict__ src, long long sk, long long sn, int K, int N, int npad,
+static __global__ void k_bimg_build(const float* __restrict__ src, long long sk, long long sn, int K, int N, int npad,
                              int kc_layout, uint4* __restrict__ img) {
     const int nkt = (K + 31) / 32;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +67,6 @@ __global__ void k_bimg_build(const float* __restrict__ src, long long sk, long l
         img[((long long)(kt * 4 + kg) * 2 + 1) * npad + n] = l;
     }
 }
-static inline size_t bimg_uint4(int K, int N) { return (size_t)((K + 31) / 32) * 4 * 2 * ((N + 3) & ~3); }
 
 // ---- operand tile: E rows x 32 k ; thread owns NP (row, k-group-of-8) pairs -------------------
 // Fast path (host-verified, see fast_ok): no divisions, no bounds branches inside the K loop.

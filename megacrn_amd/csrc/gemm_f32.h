@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kernels_api.h"
 
 namespace mcrn {
 
@@ -39,58 +40,6 @@ __device__ unsigned long long g_tl[10][512][12];   // kinds 0-2: prop_small.h ke
 #else
 #define MCRN_TL(kind, i)
 #endif
-
-struct Dim2 {          // off(i) = (i / inner) * hi + (i % inner) * lo ; inner <= 0 means plain i*lo
-    int inner;
-    long long hi;
-    long long lo;
-};
-static inline Dim2 plain(long long lo) { return Dim2{0, 0, lo}; }
-static inline Dim2 two(int inner, long long hi, long long lo) { return Dim2{inner, hi, lo}; }
-
-enum Epi { EPI_STORE = 0, EPI_GATE = 1, EPI_UPDATE = 2, EPI_BIAS = 3 };
-
-// Role tag: only changes the kernel's symbol name so that rocprofv3 --stats reports the hot
-// contractions separately (all roles share one body).
-enum Role {
-    ROLE_MISC = 0,    // adjacency / memory head / proj odds and ends
-    ROLE_PROP = 1,    // K-hop propagation  S x Z[g]            (model/MegaCRN.py:25)   <- north_star kernel
-    ROLE_WP = 2,      // weight pool + fused GRU epilogue        (model/MegaCRN.py:27,43-47)
-    ROLE_DGRAD = 3,   // dY x W^T -> plane gradients
-    ROLE_PROPT = 4,   // S^T x dZ[g]  (backward propagation)
-    ROLE_DS = 5,      // adjacency gradient  dZ x Z^T  (split-K)
-    ROLE_WGRAD = 6,   // deferred weight gradient Z^T x dY (split-K)
-    ROLE_COUNT = 7
-};
-
-struct GemmP {
-    const float* A[2];
-    const float* B[2];
-    float* C[2];
-    const float* Cin[2];        // nullable (beta ignored then)
-    long long ak_hi[2], bk_hi[2];   // per-batch override of ak.hi / bk.hi
-    Dim2 am, ak, bk, bn, cm, cn;
-    int M, N, K;
-    int nbatch, nsplit, kchunk;     // grid.z = nbatch*nsplit ; kchunk multiple of 16
-    long long slab;                 // C/Cin offset per split
-    float alpha, beta;
-    int epi;
-    // fused GRU epilogues (model/MegaCRN.py:43-47)
-    const float* bias;
-    const float* hsrc; long long hsrc_ld;     // previous state h[r*hsrc_ld + c]
-    float* out2;       long long out2_ld;     // GATE: z*h  ; UPDATE: new state
-    const float* zr;                           // UPDATE: sigmoid gates (R x 2H)
-    int H;
-    double alg_flops;   // host-side bookkeeping only (algorithmic flops of this launch)
-    int vec;            // bf16x3 path: bit0 = A rows float4-loadable, bit1 = B
-    // bf16x3 path: optional pre-split image of the B operand (static weights, gemm_bf16x3.h: k_bimg_build):
-    //   Bimg[((kt*4 + kg)*2 + hl) * bimg_n + n] = 8 bf16 (hi | lo) of B[k = 32 kt + 8 kg + 0..7][n]
-    const uint4* Bimg;
-    int bimg_n;
-    // same for a static A operand (the adjacency of the tiled propagation at N > 256), per batch, KC layout
-    const uint4* Aimg[2];
-    int aimg_n;
-};
 
 __device__ __forceinline__ long long d2off(int inner, long long hi, long long lo, int i) {
     if (inner <= 0) return (long long)i * lo;
@@ -354,11 +303,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 }
 
 // ---- host launcher ------------------------------------------------------------------------
-struct GemmStats { long long launches; double flops; };
-extern GemmStats g_gemm_stats;
-extern int g_force_cfg;   // >= 0: force this tile configuration (tuning sweeps)
-extern int g_debug;       // ablation bits for the bf16x3 kernel (0 in production)
-
 #ifndef MCRN_PROBE
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
@@ -367,10 +311,6 @@ static inline hipError_t launch_one(const GemmP& p, hipStream_t st) {
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AKC, BKC, ROLE>), grid, dim3(256), 0, st, p);
     return hipGetLastError();
 }
-// tile configurations: {BM, BN, waves in M, waves in N}
-static const int NCFG = 7;
-static const int kCfg[NCFG][4] = {{128, 128, 2, 2}, {64, 128, 2, 2}, {128, 64, 2, 2}, {64, 64, 2, 2},
-                                  {32, 128, 1, 4},  {256, 64, 4, 1}, {64, 256, 1, 4}};
 template <bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_cfg(const GemmP& p, int cfg, hipStream_t st) {
     switch (cfg) {

@@ -864,6 +864,62 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
     if (cen) cen[i] = make_uint4(wc[0], wc[1], wc[2], wc[3]);
 }
 
+// Hoisted propagation: channel block [col0, col0 + w) of the rows (n, b) of `T` plane sets, packed as the
+// [k][n] bf16 operand of the propagation GEMM:
+//   dst[n][(t*B + b)*w + j] = bf16(src[t*src_t + n*ld + b*Cp + col0 + j])      n < N, zero rows up to Kp, zero columns up to ldo
+// w == H, T == 1: the state channels of one AGCN call (the only part of the input that changes from step to step);
+// w == d, T == T_in/T_out: the input channels of every step of a stack, propagated ONCE before the recurrence.
+// 8 output elements per thread; w % 8 == 0 (and 16-byte aligned sources) takes two float4 loads.
+__global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t, int N, long long ld, int Cp, int col0, int w, int B,
+                                 int T, int Kp, int ldo, uint4* __restrict__ dst) {
+    const int c8n = ldo / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)Kp * c8n) return;
+    const int row = (int)(i / c8n), c0 = (int)(i - (long long)row * c8n) * 8;
+    const int ncols = T * B * w;
+    unsigned wd[4] = {0u, 0u, 0u, 0u};
+    if (row < N && c0 < ncols) {
+        float v[8];
+        if ((w & 7) == 0 && ((ld | Cp | col0 | src_t) & 3) == 0) {
+            const int q = c0 / w, j = c0 - q * w, t = q / B, b = q - t * B;
+            const float* sp = src + (long long)t * src_t + (long long)row * ld + (long long)b * Cp + col0 + j;
+            const float4 a = reinterpret_cast<const float4*>(sp)[0], bb = reinterpret_cast<const float4*>(sp)[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = c0 + e;
+                float x = 0.f;
+                if (c < ncols) {
+                    const int q = c / w, j = c - q * w, t = q / B, b = q - t * B;
+                    x = src[(long long)t * src_t + (long long)row * ld + (long long)b * Cp + col0 + j];
+                }
+                v[e] = x;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wd[e] = bf16_rne(v[2 * e]) | (bf16_rne(v[2 * e + 1]) << 16);
+    }
+    dst[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+// ... and the way back: the propagated input channels, tmp[(blk*N + n)][(t*B + b)*w + j] (fp32, row stride ldt), into
+// columns [col0, col0 + w) of planes 1 + blk of the plane sets of step t - of BOTH sets of a cell (gate input Z and
+// candidate input Y carry the same input channels; model/MegaCRN.py:42,45)
+__global__ void k_scatter_cols(const float* __restrict__ tmp, int ldt, int nb, int N, int B, int w, int T, float* __restrict__ Z,
+                               float* __restrict__ Y, long long dst_t, long long PS, long long ld, int Cp, int col0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)T * B * w;
+    if (i >= per * N * nb) return;
+    const long long rowi = i / per;
+    const int c = (int)(i - rowi * per);
+    const int blk = (int)(rowi / N), n = (int)(rowi - (long long)blk * N);
+    const int q = c / w, j = c - q * w, t = q / B, b = q - t * B;
+    const float v = tmp[rowi * ldt + c];
+    const long long o = (long long)t * dst_t + (long long)(1 + blk) * PS + (long long)n * ld + (long long)b * Cp + col0 + j;
+    Z[o] = v;
+    if (Y) Y[o] = v;
+}
+
 // colsum[c] = (N / nsamp) * sum over nsamp evenly spaced rows of X[row][c]: an ESTIMATE of the column sums over all N
 // rows.  The centring above is exact for ANY vector subtracted from every row (it only has to be the same vector for
 // all rows); what matters numerically is that the bulk of the common component is gone, so a 64-row sample replaces

@@ -20,20 +20,9 @@
 
 namespace mcrn {
 
-struct PropP {
-    const uint4* Sf[2][2];      // [batch][segment] fragment-ordered split adjacency
-    const float* X[2][2];       // [batch][segment] right operand plane (N x ncols, row stride ld)
-    float* C[2];
-    const float* Cin[2];        // nullable
-    int nseg;                   // 1 or 2 (K-concatenated [S_a | S_b] x [X_a ; X_b])
-    int N, ncols;
-    long long ld;
-    float alpha, beta;
-};
-
 // Sfrag[((i*KS + ks)*2 + hl)*64 + lane] = 8 bf16 of  A[row = 32 i + (lane&31)][k = 16 ks + 8 (lane>>5) + 0..7]
 // A = S (transpose == 0) or S^T (transpose == 1); out-of-range rows / k are zero.
-__global__ void k_sfrag_build(const float* __restrict__ S, long long ldS, int N, int NF, int transpose,
+static __global__ void k_sfrag_build(const float* __restrict__ S, long long ldS, int N, int NF, int transpose,
                               uint4* __restrict__ out) {
     const int KS = 2 * NF;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,14 +305,6 @@ struct PropBlock {
                 img2[(((t * KS + ks) * 2 + 1) * 64 + slot) * 2 + kq] = make_uint2(l01, l23);
             }
     }
-};
-
-struct Prop2P {
-    const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
-    float* base;                // plane set (Z for forward, dP for backward)
-    float* extra;               // backward: support 1 stores S_2^T d1t_2 here (consumers add it to dP[0])
-    long long PS, ld;
-    int N, ncols;
 };
 
 // Element addressing shared by the fused kernels.  Lane (l31, kq) of wave w owns, per column tile t and
@@ -637,15 +618,6 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
 // the B fragments of the NF waves are exchanged through a double-buffered LDS image.  Every converted
 // fragment feeds NF x 3 MFMAs (21 at N = 207) instead of 3 in the tiled GEMM: MFMA-bound by design.
 // ---------------------------------------------------------------------------------------------
-struct DsP {
-    const float* A[2][4];       // [support][segment]  (2 segments per AGCN call at cheb_k = 3; a cell's two calls share one launch)
-    const float* B[2][4];
-    float* C[2];                // slab 0 of the support; slab z at + z*slab
-    long long slab;
-    int nseg, N, ncols, kchunk; // kchunk multiple of 16
-    long long ld, ldc;
-};
-
 template <int NF>
 __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
     // LDS image of one 32-column panel of both operands, in MFMA fragment order, double-buffered:
@@ -815,14 +787,6 @@ static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st) {
 // in registers, and stores it exactly once into its own slab (plain stores: no atomics, no zero fill,
 // fixed summation order).  Per step this replaces 48 launches that each flushed a full N x N partial.
 // ---------------------------------------------------------------------------------------------
-struct DsDefP {
-    const float* dPall;          // [T][2 (0 = update AGCN, 1 = gate AGCN)][G planes]   gradient planes
-    const float* Xall[2];        // [0] = Y plane sets (update AGCN inputs), [1] = Z plane sets (gate), [T][G planes]
-    float* slabs[2];             // per support: slab z at + z*slab
-    long long slab, PS, ZT, ld, ldc;
-    int T, K, N, ncols;
-};
-
 template <int NF>
 __global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
     __shared__ uint4 img[2][NF][2][2][64];                  // one 32-column panel of both operands (see ds_small)
@@ -915,7 +879,6 @@ __global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
         }
     }
 }
-static inline int ds_deferred_chunks(int ncols) { return (ncols + 63) / 64; }
 static inline hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
@@ -933,18 +896,6 @@ static inline hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-static inline bool prop_small_ok(int N, long long ld, int ncols) {
-    return N <= 256 && (ncols % 4) == 0 && (ld % 4) == 0;
-}
-// the fused two-hop kernels (cheb_k = 3) also take 256 < N <= 352 (lo fragments of S streamed, see PropBlock::WIDE)
-static const int PROP2_MAX_N = 352;
-static inline bool prop2_ok(int N, long long ld, int ncols) {
-    return N <= PROP2_MAX_N && (ncols % 4) == 0 && (ld % 4) == 0;
-}
-static inline size_t sfrag_uint4(int N) {
-    const int NF = (N + 31) / 32;
-    return (size_t)NF * 2 * NF * 2 * 64;
-}
 static inline hipError_t launch_sfrag(const float* S, long long ldS, int N, int transpose, uint4* out, hipStream_t st) {
     const int NF = (N + 31) / 32;
     const int tot = NF * 2 * NF * 64;

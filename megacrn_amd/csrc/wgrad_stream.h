@@ -90,16 +90,25 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
 
     // ---- what this thread stages: row 4w + (lane >> 4) of every 32-row stage, columns 64 j + 4 (lane & 15)
     const int srow = 4 * w + (lane >> 4), c4 = lane & 15;
-    unsigned offA[CGA], offB[CGB];
-    bool okA[CGA], okB[CGB], oneA[CGA];
+    unsigned offB[CGB];
+    bool okA[CGA], okB[CGB], oneA[CGA], isbA[CGA];
+    const unsigned char* ptrA[CGA];                                // this thread's quad of row r0 ; row r at + (r - r0) * strA
+    int strA[CGA];
 #pragma unroll
     for (int j = 0; j < CGA; ++j) {
         const int m = m0 + 64 * j + 4 * c4;
         okA[j] = m < M;
         oneA[j] = p.ones && m == M;                                // (M % 4 == 0: the ones row is component x of its quad)
         const int mc = okA[j] ? m : 0;
-        const int g = mc / p.Cp;
-        offA[j] = (unsigned)((long long)g * p.PS + (mc - g * p.Cp));
+        const int g = mc / p.Cp, c = mc - g * p.Cp;
+        isbA[j] = p.Xb != nullptr && g >= 1 && c < p.H;            // bf16-resident state channels of a propagated plane
+        if (isbA[j]) {
+            ptrA[j] = reinterpret_cast<const unsigned char*>(p.Xb + (long long)t * p.xb_step + (long long)(g - 1) * p.xb_plane + r0 * p.H + c);
+            strA[j] = p.H * 2;
+        } else {
+            ptrA[j] = reinterpret_cast<const unsigned char*>(p.X + (long long)t * p.step_stride + (long long)g * p.PS + r0 * p.Cp + c);
+            strA[j] = p.Cp * 4;
+        }
     }
 #pragma unroll
     for (int j = 0; j < CGB; ++j) {
@@ -107,7 +116,6 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
         okB[j] = n < p.O && 64 * j + 4 * c4 < NB;
         offB[j] = okB[j] ? (unsigned)n : 0u;
     }
-    const float* __restrict__ Xt = p.X + (long long)t * p.step_stride + r0 * p.Cp;
     const float* __restrict__ Yt = p.dY + ((long long)t * p.R + r0) * p.O;
     // LDS byte offset of this thread's 8 bytes inside an image: block (k / 4 = w, col / 16), row lane >> 4, 4 columns
     const int wofs = (lane >> 4) * 32 + (c4 & 3) * 8 + (c4 >> 2) * 128;
@@ -130,7 +138,14 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
         const float rk = ok ? 1.f : 0.f;
 #pragma unroll
         for (int j = 0; j < CGA; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(Xt + (long long)rc * p.Cp + offA[j]);
+            // one 16-byte load from either source (a bf16 quad is its first 8 bytes), then a select on the VALUES
+            const float4 raw = *reinterpret_cast<const float4*>(ptrA[j] + (long long)rc * strA[j]);
+            const unsigned u0 = __float_as_uint(raw.x), u1 = __float_as_uint(raw.y);
+            float4 v;
+            v.x = isbA[j] ? __uint_as_float(u0 << 16) : raw.x;
+            v.y = isbA[j] ? __uint_as_float(u0 & 0xFFFF0000u) : raw.y;
+            v.z = isbA[j] ? __uint_as_float(u1 << 16) : raw.z;
+            v.w = isbA[j] ? __uint_as_float(u1 & 0xFFFF0000u) : raw.w;
             const float k = rk * mkA[j];
             const float x_ = v.x * k;
             va[j] = make_float4(oneA[j] ? rk : x_, v.y * k, v.z * k, v.w * k);   // (a select: the fused form became v_pk_fma_f32, see launch_wgrad_one)
@@ -308,6 +323,7 @@ hipError_t launch_wgrad_stream(const WgradP& p, hipStream_t st) {
     if (!wgrad_stream_ok(p.G, p.Cp, p.O) || p.kch <= 0 || (p.kch & 31) || p.cpt <= 0) return hipErrorInvalidValue;
     if ((((uintptr_t)p.X) | ((uintptr_t)p.dY)) & 15) return hipErrorInvalidValue;
     if (((p.step_stride | p.PS) & 3) != 0) return hipErrorInvalidValue;
+    if (p.Xb && ((p.H & 3) || (((uintptr_t)p.Xb) & 7) || ((p.xb_step | p.xb_plane) & 3))) return hipErrorInvalidValue;
     const int M = p.G * p.Cp + (p.ones ? 1 : 0);
     if (p.O <= 32) return M <= 256 ? launch_wgrad_one<1, 1, 1>(p, st) : launch_wgrad_one<2, 1, 1>(p, st);   // 256 / 512 x 32
     if (p.O <= 64) return M <= 256 ? launch_wgrad_one<2, 1, 2>(p, st) : launch_wgrad_one<3, 1, 2>(p, st);   // 256 / 384 x 64

@@ -20,6 +20,12 @@ struct WgradP {
     int cpt, kch;             // kch % 32 == 0
     int ones;                 // 1: X gets a virtual all-ones column, i.e. row G*Cp of every slab = column sums of dY (the bias
                               //    gradient, model/MegaCRN.py:28) - dY is in LDS anyway, a separate column-sum pass re-read it
+    // MCRN_BF16, bf16-resident propagated planes (wp_stream.h): when Xb != null, the state channels c < H of the planes
+    // g >= 1 are read from  Xb[t * xb_step + (g - 1) * xb_plane + r * H + c]  (bf16) instead of X; plane 0 and the input
+    // channels [H, Cp) of every plane still come from X.  (16 readable bytes are assumed behind every 8-byte quad.)
+    const unsigned short* Xb;
+    long long xb_step, xb_plane;
+    int H;
 };
 
 // shapes the kernel takes: O <= 512, O % 4 == 0, Cp % 4 == 0, 16-byte aligned bases

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dYd, hY.data(), hY.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dS, 0xFF, (size_t)nslab * M * O * 4));
-    WgradP p; p.X = dX; p.step_stride = ZT; p.PS = PS; p.Cp = Cp; p.G = G; p.T = T; p.R = R; p.dY = dYd; p.O = O; p.slabs = dS;
+    WgradP p; memset(&p, 0, sizeof p); p.X = dX; p.step_stride = ZT; p.PS = PS; p.Cp = Cp; p.G = G; p.T = T; p.R = R; p.dY = dYd; p.O = O; p.slabs = dS;
     p.cpt = cpt; p.kch = kch; p.ones = 1;
     hipError_t e = launch_wgrad_stream(p, 0);
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 2; }

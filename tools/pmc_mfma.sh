@@ -1,0 +1,39 @@
+#!/bin/bash
+# MFMA utilisation of the IN-MODEL launches of a short bench run (north_star: "rocprof ... MFMA utilisation"):
+#   SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel, over the LAST `keep` dispatches of every kernel name (the train
+#   steps at the end of the run; the one-off tile autotune at its start launches the same kernels on scratch data).
+# Counters only (--pmc with --kernel-trace; no other trace domain).  usage: tools/pmc_mfma.sh <tag> [bench args]
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcm_${tag} -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary "$@" > /dev/null 2>&1
+python3 - "$tag" <<'PY'
+import csv, glob, sys, os, collections, re
+tag = sys.argv[1]
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
+rows = collections.defaultdict(lambda: collections.defaultdict(dict))      # name -> dispatch -> counter -> value
+for f in glob.glob(f"{root}/pmcm_{tag}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mcrn::", "").replace("mcrn::", "")
+        rows[n][int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+out = []
+for n, disp in rows.items():
+    ids = sorted(disp)
+    keep = ids[-min(len(ids), 48):]
+    agg = collections.Counter()
+    for i in keep:
+        for c, v in disp[i].items():
+            agg[c] += v
+    k = len(keep)
+    busy, mf = agg.get("SQ_BUSY_CYCLES", 0.0), agg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    if mf <= 0:
+        continue
+    out.append((mf, n, k, mf / k, busy / k, agg.get("GRBM_GUI_ACTIVE", 0.0) / k, agg.get("SQ_WAVE_CYCLES", 0.0) / k,
+                agg.get("SQ_WAIT_ANY", 0.0) / k, agg.get("SQ_WAIT_INST_ANY", 0.0) / k))
+lines = ["kernel | dispatches averaged | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | MFMA busy / (GUI_ACTIVE x 256 CU x 4 SIMD) | WAIT_ANY/WAVE_CYCLES | WAIT_INST_ANY/WAVE_CYCLES"]
+for mf, n, k, mfa, busy, gui, wc, wa, wi in sorted(out, reverse=True)[:24]:
+    util = mfa / (gui * 1024.0) if gui else 0.0
+    lines.append(f"{n[:72]:72s} | {k:3d} | {mfa:14.0f} | {busy:12.0f} | {gui:9.0f} | {100 * util:5.1f} % | {wa / wc if wc else 0:5.2f} | {wi / wc if wc else 0:5.2f}")
+open(f"{root}/mfma_{tag}.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmcm_${tag}
