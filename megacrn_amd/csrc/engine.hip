@@ -368,6 +368,13 @@ struct Bf16Key {
     bool operator<(const Bf16Key& o) const { return memcmp(this, &o, sizeof(Bf16Key)) < 0; }
 };
 static std::map<Bf16Key, int> g_tuned_bf16;
+static float g_last_tune_ms = 0.f;                     // best time of the signature bf16_gemm tuned last
+// Tuning under the cache conditions of the model: between two launches of the same product a step streams 100+ MB
+// through the L2s, so its operands come from the memory side - back-to-back trial launches would rank the tiles by their
+// L2-hot time (measured at N = 1843: 46 us hot vs 54 us in the step for the same tile).  mcrn_model_autotune provides a
+// scratch buffer; every timed trial launch is preceded by a fill of it.
+static char* g_flush = nullptr;
+static size_t g_flush_bytes = 0;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
@@ -403,16 +410,30 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                 for (int c = 0; c < NCFG_BF16; ++c) {
                     if (bf16_cfg_is_sk(c)) continue;
                     CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));                   // warm-up
-                    CK(hipEventRecord(g_tune_ev[0], st));
-                    for (int r = 0; r < 5; ++r) CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));
-                    CK(hipEventRecord(g_tune_ev[1], st));
-                    CK(hipEventSynchronize(g_tune_ev[1]));
                     float ms = 0;
-                    CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                    if (g_flush) {
+                        for (int r = 0; r < 5; ++r) {
+                            CK(hipMemsetAsync(g_flush, r, g_flush_bytes, st));           // operands leave the L2s, as in a step
+                            CK(hipEventRecord(g_tune_ev[0], st));
+                            CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));
+                            CK(hipEventRecord(g_tune_ev[1], st));
+                            CK(hipEventSynchronize(g_tune_ev[1]));
+                            float m1 = 0;
+                            CK(hipEventElapsedTime(&m1, g_tune_ev[0], g_tune_ev[1]));
+                            ms += m1;
+                        }
+                    } else {
+                        CK(hipEventRecord(g_tune_ev[0], st));
+                        for (int r = 0; r < 5; ++r) CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));
+                        CK(hipEventRecord(g_tune_ev[1], st));
+                        CK(hipEventSynchronize(g_tune_ev[1]));
+                        CK(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                    }
                     if (ms < cfg_ms[c]) cfg_ms[c] = ms;
                 }
             for (int c = 0; c < NCFG_BF16; ++c)
                 if (cfg_ms[c] < best_ms) { best_ms = cfg_ms[c]; cfg = c; }
+            g_last_tune_ms = best_ms;
             if (getenv("MCRN_TUNE_LOG")) {
                 fprintf(stderr, "[mcrn tune] bf16 %s role %d M=%d N=%d K=%dx%d split=%d:", btr ? "nn" : "nt", role, p.M, p.N, p.nseg,
                         p.seg_len, nsplit);
@@ -483,6 +504,7 @@ static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, ui
 // MCRN_BF16, hoisted input channels: columns [col0, col0 + w) of plane 0 of the T plane sets Z[t] (stride s.ZT) are
 // propagated in ONE product  [S1; T2(S1); S2; T2(S2)] x [N x T*B*w]  and written to the same columns of planes 1 .. nb of
 // Z[t] and Y[t] (gate and candidate input share their input channels, model/MegaCRN.py:42,45).
+static const int HOIST_MAX_SPLIT = 8;
 static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, uint16_t* xin_b, float* xin_t,
                         hipStream_t st) {
     if (!s.hoist || w <= 0 || T <= 0) return 0;
@@ -494,29 +516,61 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     p.B = xin_b; p.ldb = ncp; p.N = ncp;
     p.nseg = 1; p.seg_len = s.N;
     p.C = xin_t; p.cm = rm_plain(ncp);
-    CKI(bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));
+    // a narrow product (T*B*w = 32 .. 400 columns against 7372 rows at N = 1843): split K so that it still fills the chip
+    const long long tiles = (long long)cdiv(p.M, 256) * cdiv(ncp, 128);
+    int nsplit = (int)((240 + tiles / 2) / tiles);
+    nsplit = nsplit < 1 ? 1 : (nsplit > HOIST_MAX_SPLIT ? HOIST_MAX_SPLIT : nsplit);
+    // splits the launcher really makes (bf16_split_plan) for a K tile of 64 and of 32: the consumer below must know the count
+    // whatever tile configuration the tuner picks, so a request that the two depths would round differently is not split
+    auto eff = [&](int bk) { const int kt = cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
+    if (eff(64) != eff(32)) nsplit = 1;
+    const int nsp = eff(64);
+    p.slab = (long long)p.M * ncp;
+    CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));
     const long long tot = (long long)u.nb * s.N * ncols;
-    LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, u.nb, s.N, s.B, w, T, Z, Y, s.ZT, s.PS,
-           s.ld, s.Cp, col0);
+    LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Z, Y,
+           s.ZT, s.PS, s.ld, s.Cp, col0);
     return 0;
 }
 // MCRN_BF16 backward propagation: dP[0] += [S1^T | T2(S1)^T | S2^T | T2(S2)^T] x [dP[1]; ..; dP[nb]]  (K = nb*N)
 // The output is only N x B*Cp (135 / 255 tiles of 128 x 128 at EXPY-TKY) while K is nb*N deep: K is split in two, the
 // second half lands in the extra plane dT that the element-wise consumers of dP[0] add (same mechanism as the fused
 // S^T chain of the small-graph path), so no reduction pass and still one writer per element.
-static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, bool* used_dT, hipStream_t st) {
+static const int PROPT_MAX_X = 3;                       // extra partial planes behind dT (K splits 1 .. 3)
+struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
+static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
+static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, int* used_dT, hipStream_t st) {
     Bf16GemmP p = bgp(u);
     p.A = u.STstk; p.am = rm_plain((long long)u.nb * u.Kp); p.M = s.N;
     p.B = dPb; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PSb;
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
     int nsplit = 1;
-    static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 2;
-    if (dT && used_dT && split_env == 2 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
-        nsplit = 2; p.slab = dT - dP; p.cin_first_only = 1;
-        *used_dT = true;
+    static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 0;   // 0: tuned (2 .. 4)
+    const double alg = (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
+    if (dT && used_dT && split_env != 1 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
+        // The output is only N x B*Cp while K is nb*N deep: K is split, split 0 accumulates into plane 0, the others land in
+        // the extra planes dT .. that the element-wise consumers of plane 0 add in a fixed order (no reduction pass, one
+        // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
+        p.slab = dT - dP; p.slab2 = s.PS; p.cin_first_only = 1;
+        const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N};
+        nsplit = split_env >= 2 && split_env <= 1 + PROPT_MAX_X ? split_env : 2;
+        if (split_env == 0) {
+            auto it = g_tuned_split.find(key);
+            if (it != g_tuned_split.end()) nsplit = it->second;
+            else if (g_tuning) {
+                float best = 1e30f;
+                for (int ns = 2; ns <= 1 + PROPT_MAX_X; ++ns) {
+                    CKI(bf16_gemm(p, true, ns, ROLE_PROPT, alg, st));        // tunes the tile for this split count
+                    if (g_last_tune_ms < best) { best = g_last_tune_ms; nsplit = ns; }
+                }
+                g_tuned_split[key] = nsplit;
+                if (getenv("MCRN_TUNE_LOG")) fprintf(stderr, "[mcrn tune] role 4 M=%d N=%d: %d K splits\n", p.M, p.N, nsplit);
+            }
+        }
+        *used_dT = nsplit - 1;
     }
-    return bf16_gemm(p, true, nsplit, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+    return bf16_gemm(p, true, nsplit, ROLE_PROPT, alg, st);
 }
 // MCRN_BF16 adjacency gradient of a whole cell stack, ONE launch: K runs over every AGCN call of the stack
 //   dA[b] (N x N) (+)= sum_calls dP_call[1 + b] (N x B*Cp) x (X0_call - mean)^T        b < nb
@@ -601,9 +655,9 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
-                         float* dT = nullptr, bool* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
+                         float* dT = nullptr, int* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
                          bool cell_ds_last = true) {
-    if (used_dT) *used_dT = false;
+    if (used_dT) *used_dT = 0;
     bool dgrad_wrote_bf16 = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
@@ -638,7 +692,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
         q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
-        if (used_dT) *used_dT = true;
+        if (used_dT) *used_dT = 1;
         const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
     } else if (s.K == 3 && small) {
@@ -909,11 +963,11 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
 static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float* Y, const float* zr,
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
-                         float* dTg = nullptr, bool do_a = true, bool do_c = true, bool* xu_out = nullptr,
-                         bool* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */,
+                         float* dTg = nullptr, bool do_a = true, bool do_c = true, int* xu_out = nullptr,
+                         int* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */,
                          int pair = 0 /* which (dP, dQ) plane-set pair the caller handed in: event slots 2*pair, 2*pair+1 */) {
     const long long RH = s.R * s.H;
-    bool xu = false, xg = false;
+    int xu = 0, xg = 0;                       // extra partial planes of plane 0 behind dTu / dTg (stride s.PS)
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     DsP cell_ds;
     cell_ds.nseg = 0;
@@ -924,21 +978,21 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     static const bool merge_ds = !(getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0);
     DsP* cds = merge_ds ? &cell_ds : nullptr;
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
-    LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true));
-    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)(xg ? dTg : nullptr), (const float*)dP, (const float*)(xu ? dTu : nullptr), (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
     return 0;
 }
 // C of the step just finished (its planes dP / dQ, extra planes dTu / dTg when xu / xg) + projection backward
 // (decoder: Wp != null) + A of the next step to process (saved Z / zr / hc of that step)
-static int cell_bwd_ca(const Shp& s, const float* dP, const float* dQ, const float* dTu, const float* dTg, bool xu, bool xg,
+static int cell_bwd_ca(const Shp& s, const float* dP, const float* dQ, const float* dTu, const float* dTg, int xu, int xg,
                        const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
                        float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
                        float* dacc, hipStream_t st) {
-    LAUNCH(k_cell_bwd_ca, dim3(cdiv(s.R * s.H, 256)), dim3(256), 0, st, dQ, (const float*)(xg ? dTg : nullptr), dP,
-           (const float*)(xu ? dTu : nullptr), (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
+    LAUNCH(k_cell_bwd_ca, dim3(cdiv(s.R * s.H, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
+           dTu, xu, s.PS, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
            Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     return 0;
 }
@@ -1211,8 +1265,8 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     for (int i = 1; i < ModelPlan::NPAIR; ++i) { P.dPp[i] = b.take<float>(zmax); P.dQp[i] = b.take<float>(zmax); }
     {
         size_t pmax = (size_t)(P.se.PS > P.sd.PS ? P.se.PS : P.sd.PS);
-        P.dTu = b.take<float>(pmax);
-        P.dTg = b.take<float>(pmax);
+        P.dTu = b.take<float>(pmax * PROPT_MAX_X);        // extra partial planes of plane 0 (K splits 1 .. 3 / second support)
+        P.dTg = b.take<float>(pmax * PROPT_MAX_X);
     }
     P.dPall_e = P.dSdef = nullptr;
     P.dPall_d = P.defer_ds ? b.take<float>((size_t)d->T_out * 2 * P.sd.ZT) : nullptr;
@@ -1250,7 +1304,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
             const long long ce = (long long)d->T_in * B * d->input_dim, cd = (long long)d->T_out * B * (od + yd);
             const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 7) & ~7LL) + 8;
             P.xin_b = b.take<uint16_t>((size_t)P.Kp * ncp);
-            P.xin_t = b.take<float>((size_t)P.nb * N * ncp);
+            P.xin_t = b.take<float>((size_t)8 /* HOIST_MAX_SPLIT */ * P.nb * N * ncp);
         }
         P.Sstk = b.take<uint16_t>((size_t)P.nb * N * P.Kp);
         P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
@@ -1608,7 +1662,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     Sup ud = u; ud.defer = P.defer_ds;
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
     {
-        bool xu = false, xg = false;
+        int xu = 0, xg = 0;
         const float *dPprev = nullptr, *dQprev = nullptr;
         for (int t = To - 1; t >= 0; --t) {
             const bool last = t == To - 1;
@@ -1681,7 +1735,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // ---- encoder BPTT
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     {
-        bool xu = false, xg = false;
+        int xu = 0, xg = 0;
         for (int t = Ti - 1; t >= 0; --t) {
             const bool first = t == Ti - 1;
             const int pair = t % ModelPlan::NPAIR, prev = (t + 1) % ModelPlan::NPAIR;   // (the cell processed just before: t + 1)
@@ -1881,17 +1935,22 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
     mcrn_grads_t G = {gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9], gg[10], gg[11], gg[12], gg[13]};
     PrecisionScope prec(d->precision);
     g_tuning = true;
+    if (d->precision == MCRN_BF16 && !(getenv("MCRN_TUNE_COLD") && atoi(getenv("MCRN_TUNE_COLD")) == 0)) {
+        g_flush_bytes = (size_t)192 << 20;
+        if (hipMalloc(&g_flush, g_flush_bytes) != hipSuccess) { g_flush = nullptr; g_flush_bytes = 0; (void)hipGetLastError(); }
+    }
     int rc = model_forward(d, &P, x, yc, nullptr, nullptr, (char*)ws, out, o4[0], o4[1], o4[2], o4[3], st);
     if (!rc) rc = model_backward(d, &P, nullptr, dout, nullptr, dq, nullptr, nullptr, (char*)ws, &G, st);
     g_tuning = false;
+    if (g_flush) { (void)hipStreamSynchronize(st); (void)hipFree(g_flush); g_flush = nullptr; g_flush_bytes = 0; }
     g_force_cfg = -1;                     // a failed trial launch may have left the tuning loop's value behind
     if (rc) { (void)hipStreamSynchronize(st); side_reset(); }
     (void)hipStreamSynchronize(st);
     (void)hipFree(buf);
     return rc;
 }
-int mcrn_autotune_entries(void) { return (int)(g_tuned.size() + g_tuned_bf16.size()); }
-int mcrn_autotune_clear(void) { g_tuned.clear(); g_tuned_bf16.clear(); return 0; }
+int mcrn_autotune_entries(void) { return (int)(g_tuned.size() + g_tuned_bf16.size() + g_tuned_split.size()); }
+int mcrn_autotune_clear(void) { g_tuned.clear(); g_tuned_bf16.clear(); g_tuned_split.clear(); return 0; }
 // Tile table as a flat int32 record list: {kind, nkey, key..., cfg}.  Data-parallel ranks tune independently (timing noise
 // can pick different tiles, hence different fp32 summation orders); rank 0 exports, the others import (dp / bench.py).
 long long mcrn_autotune_export(int* buf, long long cap) {
@@ -1910,6 +1969,13 @@ long long mcrn_autotune_export(int* buf, long long cap) {
         for (int i = 0; i < nk; ++i) out.push_back(k[i]);
         out.push_back(kv.second);
     }
+    for (const auto& kv : g_tuned_split) {
+        const int* k = reinterpret_cast<const int*>(&kv.first);
+        const int nk = (int)(sizeof(SplitKey) / sizeof(int));
+        out.push_back(2); out.push_back(nk);
+        for (int i = 0; i < nk; ++i) out.push_back(k[i]);
+        out.push_back(kv.second);
+    }
     if (buf && cap >= (long long)out.size()) memcpy(buf, out.data(), out.size() * sizeof(int));
     return (long long)out.size();
 }
@@ -1917,23 +1983,28 @@ int mcrn_autotune_import(const int* buf, long long n) {
     if (!buf || n < 0) FAIL("autotune_import: bad arguments");
     std::map<TuneKey, int> a;
     std::map<Bf16Key, int> b;
+    std::map<SplitKey, int> c;
     long long i = 0;
     while (i < n) {
         if (i + 2 > n) FAIL("autotune_import: truncated record");
         const int kind = buf[i], nk = buf[i + 1];
-        const int want = kind == 0 ? (int)(sizeof(TuneKey) / sizeof(int)) : kind == 1 ? (int)(sizeof(Bf16Key) / sizeof(int)) : -1;
+        const int want = kind == 0 ? (int)(sizeof(TuneKey) / sizeof(int)) : kind == 1 ? (int)(sizeof(Bf16Key) / sizeof(int)) :
+                         kind == 2 ? (int)(sizeof(SplitKey) / sizeof(int)) : -1;
         if (nk != want || i + 2 + nk + 1 > n) FAIL("autotune_import: malformed record at word %lld", i);
         const int cfg = buf[i + 2 + nk];
         if (kind == 0) {
             if (cfg < 0 || cfg >= NCFG) FAIL("autotune_import: tile configuration %d out of range", cfg);
             TuneKey k; memcpy(&k, buf + i + 2, sizeof k); a[k] = cfg;
-        } else {
+        } else if (kind == 1) {
             if (cfg < 0 || cfg >= NCFG_BF16) FAIL("autotune_import: bf16 tile configuration %d out of range", cfg);
             Bf16Key k; memcpy(&k, buf + i + 2, sizeof k); b[k] = cfg;
+        } else {
+            if (cfg < 1 || cfg > 1 + PROPT_MAX_X) FAIL("autotune_import: split count %d out of range", cfg);
+            SplitKey k; memcpy(&k, buf + i + 2, sizeof k); c[k] = cfg;
         }
         i += 2 + nk + 1;
     }
-    g_tuned.swap(a); g_tuned_bf16.swap(b);
+    g_tuned.swap(a); g_tuned_bf16.swap(b); g_tuned_split.swap(c);
     return 0;
 }
 int mcrn_set_precision(int precision) {

@@ -226,8 +226,9 @@ template <int FM, int FN>
 __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int split, int r_base, int c_base,
                                               int lane) {
     const int l31 = lane & 31, kq = lane >> 5;
-    float* __restrict__ C = p.C ? p.C + (long long)split * p.slab : nullptr;
-    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + (long long)split * p.slab : nullptr;
+    const long long soff = p.slab2 > 0 ? (split > 0 ? p.slab + (long long)(split - 1) * p.slab2 : 0) : (long long)split * p.slab;
+    float* __restrict__ C = p.C ? p.C + soff : nullptr;
+    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
     const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
     const bool cols_in = cw + 32 * FN <= p.N;

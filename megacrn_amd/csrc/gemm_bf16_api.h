@@ -38,6 +38,8 @@ struct Bf16GemmP {
     float alpha, beta;
     int nsplit, tiles_per_split;   // split-K over k-tiles ; C / Cin of split z at + z * slab
     long long slab;
+    long long slab2;          // > 0: split z >= 1 lands at C + slab + (z - 1) * slab2 (split 0 at C): the partial sums of a product
+                              //      whose first slab is the real output and whose further slabs are a separate run of planes
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
     int xcd;                  // 1: XCD-aware tile order

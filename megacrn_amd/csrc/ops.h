@@ -535,7 +535,9 @@ __global__ void k_cell_bwd_a(const float* __restrict__ dhn, const float* __restr
     dacc[i] = g * rr;
 }
 // B: dzh = dY0[state part] ; dG[:, :H] = dzh*h*z*(1-z) ; dacc += dzh*z
-__global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ldy,
+// (dy0x: `nx` extra planes `xs` floats apart that hold further partial sums of plane 0: the second support's S^T
+//  contribution of prop2_bwd_kernel, or the K splits 1 .. nx of the bf16 transposed propagation)
+__global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restrict__ dy0x, int nx, long long xs, long long ldy,
                              const float* __restrict__ z0, long long ldz, const float* __restrict__ zr, int H,
                              long long R, float* __restrict__ dG, float* __restrict__ dacc) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,15 +545,15 @@ __global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restr
     int c = (int)(i % H);
     long long r = i / H;
     float dzh = dy0[r * ldy + c];
-    if (dy0x) dzh += dy0x[r * ldy + c];          // second support's S^T contribution (prop2_bwd_kernel)
+    for (int e = 0; e < nx; ++e) dzh += dy0x[e * xs + r * ldy + c];
     float h = z0[r * ldz + c];
     float z = zr[r * 2 * H + c];
     dG[r * 2 * H + c] = dzh * h * z * (1.f - z);
     dacc[i] += dzh * z;
 }
 // C: dh_prev = dacc + dZ0[state] ; dxin = dY0[input] + dZ0[input]
-__global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dz0x,
-                             const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ld,
+__global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
+                             const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, long long ld,
                              int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int C = H + d;
@@ -559,11 +561,11 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
     int c = (int)(i % C);
     long long r = i / C;
     float a = dz0[r * ld + c];
-    if (dz0x) a += dz0x[r * ld + c];
+    for (int e = 0; e < nzx; ++e) a += dz0x[e * xs + r * ld + c];
     if (c < H) dacc[r * H + c] += a;
     else {
         float b = dy0[r * ld + c];
-        if (dy0x) b += dy0x[r * ld + c];
+        for (int e = 0; e < nyx; ++e) b += dy0x[e * xs + r * ld + c];
         dxin[r * d + (c - H)] = a + b;
     }
 }
@@ -574,8 +576,8 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
 //   dh      = dacc + dZ0[state]                                    (C)
 //   dgo_j   = d_out[b,t,n,j] + (use_next ? dY0[in j] + dZ0[in j] : 0) ; dh += sum_j dgo_j Wp[j][c]   (k_proj_bwd)
 //   dU, dG[:,H:], dacc from dh and step t's saved z0 / zr / hc     (A)
-__global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __restrict__ dz0x,
-                              const float* __restrict__ dy0, const float* __restrict__ dy0x, long long ld,
+__global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
+                              const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, long long ld,
                               const float* __restrict__ dout_bt, long long out_sb, long long out_sn, int use_next,
                               const float* __restrict__ Wp, int od, float* __restrict__ dgo_rows, int B,
                               const float* __restrict__ z0, long long ldz, const float* __restrict__ zr,
@@ -586,7 +588,7 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
     const int c = (int)(i % H);
     const long long r = i / H;
     float a = dz0[r * ld + c];
-    if (dz0x) a += dz0x[r * ld + c];
+    for (int e = 0; e < nzx; ++e) a += dz0x[e * xs + r * ld + c];
     float g = dacc[i] + a;
     if (Wp) {
         const int n = (int)(r / B), b = (int)(r % B);
@@ -594,8 +596,8 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
             float go = dout_bt[b * out_sb + n * out_sn + j];
             if (use_next) {
                 float x = dz0[r * ld + H + j] + dy0[r * ld + H + j];
-                if (dz0x) x += dz0x[r * ld + H + j];
-                if (dy0x) x += dy0x[r * ld + H + j];
+                for (int e = 0; e < nzx; ++e) x += dz0x[e * xs + r * ld + H + j];
+                for (int e = 0; e < nyx; ++e) x += dy0x[e * xs + r * ld + H + j];
                 go += x;
             }
             g += go * Wp[(long long)j * H + c];
@@ -902,11 +904,12 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
     }
     dst[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
 }
-// ... and the way back: the propagated input channels, tmp[(blk*N + n)][(t*B + b)*w + j] (fp32, row stride ldt), into
+// ... and the way back: the propagated input channels, tmp[(blk*N + n)][(t*B + b)*w + j] (fp32, row stride ldt; the sum of
+// `nsplit` split-K partial products `slab` floats apart), into
 // columns [col0, col0 + w) of planes 1 + blk of the plane sets of step t - of BOTH sets of a cell (gate input Z and
 // candidate input Y carry the same input channels; model/MegaCRN.py:42,45)
-__global__ void k_scatter_cols(const float* __restrict__ tmp, int ldt, int nb, int N, int B, int w, int T, float* __restrict__ Z,
-                               float* __restrict__ Y, long long dst_t, long long PS, long long ld, int Cp, int col0) {
+__global__ void k_scatter_cols(const float* __restrict__ tmp, int ldt, int nsplit, long long slab, int nb, int N, int B, int w, int T,
+                               float* __restrict__ Z, float* __restrict__ Y, long long dst_t, long long PS, long long ld, int Cp, int col0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)T * B * w;
     if (i >= per * N * nb) return;
@@ -914,7 +917,8 @@ __global__ void k_scatter_cols(const float* __restrict__ tmp, int ldt, int nb, i
     const int c = (int)(i - rowi * per);
     const int blk = (int)(rowi / N), n = (int)(rowi - (long long)blk * N);
     const int q = c / w, j = c - q * w, t = q / B, b = q - t * B;
-    const float v = tmp[rowi * ldt + c];
+    float v = tmp[rowi * ldt + c];
+    for (int z = 1; z < nsplit; ++z) v += tmp[z * slab + rowi * ldt + c];      // split-K partial products, fixed order
     const long long o = (long long)t * dst_t + (long long)(1 + blk) * PS + (long long)n * ld + (long long)b * Cp + col0 + j;
     Z[o] = v;
     if (Y) Y[o] = v;

@@ -773,7 +773,11 @@ def test_bf16_mode_full_size_properties(name):
 # dS: the fp32 summation ORDER of the adjacency-gradient product (K = 2T*B*Cp, cut differently for a
 # half batch) is amplified by that factor.  bf16x3 accumulates dS per call into slabs in a batch-independent order; the
 # bf16 mode's one product per stack does not, hence its own bound (measured 1.2e-3 at N = 1843, B = 32).
-ADD_TOL = {"bf16x3": (1e-4, 1e-4), "bf16": (1e-4, 1e-2)}
+# bf16 mode, all tensors: the half batches are different GEMM shapes, for which the tuner may choose another tile / K split
+# of the transposed propagation; the fp32 partial sums then differ in their last bit, and where such a value is rounded
+# to a bf16 operand (the gradient planes) the rounding can flip (2^-9 relative): additivity holds to the mode's
+# arithmetic (measured 2e-4 .. 5e-4), not to fp32 round-off (7e-6 when both shapes happen to split alike).
+ADD_TOL = {"bf16x3": (1e-4, 1e-4), "bf16": (2e-3, 1e-2)}
 
 
 @pytest.mark.parametrize("name,mode", [("pemsbay", "bf16x3"), ("expytky", "bf16x3"), ("expytky", "bf16"), ("syn8192", "bf16")])
