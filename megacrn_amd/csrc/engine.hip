@@ -284,6 +284,8 @@ struct Shp {   // one AGCN / cell geometry
     int Kp; long long ldp, PSb;   // MCRN_BF16: bf16 planes are [Kp = roundup(N, 64)][ldp = roundup(ld, 64)], zero padded
     bool hoist; long long ldh;    // MCRN_BF16, H % 32 == 0: the per-step propagation covers the B*H state columns only (ldh);
                                   // the input channels of every step are propagated once per stack
+    bool fused;                   // bf16x3, N <= 256, cheb_k = 3: one launch per AGCN call (agcn_fused.h); the input (and pad)
+                                  // channels of every step are propagated once per stack here too
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
 };
@@ -302,6 +304,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     static const bool hoist_off = getenv("MCRN_HOIST") && atoi(getenv("MCRN_HOIST")) == 0;
     s.hoist = bf16_rows && !hoist_off && (H % 32) == 0 && d > 0;
     s.ldh = (long long)B * H;
+    s.fused = false;              // (set by plan_model: needs both output widths of the cell and the session precision)
     static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
     s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
@@ -529,6 +532,28 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));
     const long long tot = (long long)u.nb * s.N * ncols;
     LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Z, Y,
+           s.ZT, s.PS, s.ld, s.Cp, col0);
+    return 0;
+}
+// Small graphs with the fused AGCN kernel: the same hoisting in fp32 / bf16x3.  Columns [col0, col0 + w) of plane 0 of T plane
+// sets are packed into an N x (T*B*w) matrix, propagated by the fused two-hop kernel (planes 1 .. 4 of the scratch set) and
+// scattered into planes 1 .. 4 of Z[t] and Y[t].  The pad channels ride along (w reaches Cp): S x 0 = 0 is what the
+// unfused propagation wrote there, and the adjacency gradient reads those columns.
+static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b, uint16_t* x0c, uint16_t* Pb, bool packed);
+static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, float* xin_f, hipStream_t st) {
+    if (!s.fused || w <= 0 || T <= 0) return 0;
+    const int ncols = T * s.B * w;
+    const int ncp = (ncols + 3) & ~3;
+    const long long tot0 = (long long)s.N * ncp;
+    LAUNCH(k_pack_cols_f32, dim3(cdiv(tot0, 256)), dim3(256), 0, st, (const float*)Z, s.ZT, s.N, s.ld, s.Cp, col0, w, s.B, T, ncp, xin_f);
+    Shp t = s;
+    t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false;
+    Prop2P q;
+    q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
+    const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
+    MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
+    const long long tot = (long long)4 * s.N * ncols;
+    LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)(xin_f + t.PS), ncp, 1, 0LL, 4, s.N, s.B, w, T, Z, Y,
            s.ZT, s.PS, s.ld, s.Cp, col0);
     return 0;
 }
@@ -907,6 +932,19 @@ static int centre_planes(const Shp& s, const Sup& u, const float* Zall, const fl
 }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
+// one AGCN call as one launch (agcn_fused.h): propagation of both supports + weight pool + GRU epilogue
+static int agcn_fused(const Shp& s, const Sup& u, float* Z, const uint4* img, const float* bias, int epi, float* out, float* out2,
+                      long long out2_ld, const float* hsrc, long long hsrc_ld, const float* zr, hipStream_t st) {
+    AgcnFP q;
+    memset(&q, 0, sizeof q);
+    q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.Z = Z; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.B = s.B; q.H = s.H; q.d = s.d; q.Cp = s.Cp;
+    q.O = epi == AGF_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
+    q.out = out; q.out2 = out2; q.out2_ld = out2_ld; q.hsrc = hsrc; q.hsrc_ld = hsrc_ld; q.zr = zr;
+    const double prop = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;              // 2 hops x 2 supports, state channels
+    const double wp = 2.0 * (double)s.R * (2.0 * s.K * s.C) * q.O;
+    MCRN_PROF_WRAP(ROLE_PROP, launch_agcn_fused(q, st), prop * (q.O / 64) + wp, prop + wp);
+    return 0;
+}
 struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr;
                const uint4 *wp_g = nullptr, *wp_u = nullptr; /* weight images of the streaming weight pool (wp_stream.h) */ };
 // streaming weight pool on bf16-resident planes (wp_stream.h) with the library's profiling hooks
@@ -935,6 +973,12 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
         CKI(wp_stream(s, u, Z, Pb, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, x0b + s.PSb, nullptr, 0, nullptr, st));
         CKI(prop_fwd(s, u, Y, st, x0b + s.PSb, x0c ? x0c + s.PSb : nullptr, Pb + PbS, true));
         CKI(wp_stream(s, u, Y, Pb + PbS, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, x0b_next, Z, s.Cp, zr, st));
+        return 0;
+    }
+    static const int fused_maxh = getenv("MCRN_AGCN_FUSED_MAXH") ? atoi(getenv("MCRN_AGCN_FUSED_MAXH")) : 1 << 30;   // A/B: fuse cells up to this width only
+    if (s.fused && s.H <= fused_maxh && w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && !g_prop_bf16 && u.Sf[0] && aligned16(Z) && aligned16(Y)) {
+        CKI(agcn_fused(s, u, Z, w.wp_g, w.bg, AGF_GATE, zr, Y, s.Cp, nullptr, 0, nullptr, st));
+        CKI(agcn_fused(s, u, Y, w.wp_u, w.bu, AGF_UPDATE, hc, hnext, hnext_ld, Z, s.Cp, zr, st));
         return 0;
     }
     static const int wp_dbg = getenv("MCRN_WP_DBG") ? atoi(getenv("MCRN_WP_DBG")) : 3;   // debugging: bit 0 = H <= 64 cells, bit 1 = H > 64 cells
@@ -1202,6 +1246,7 @@ struct ModelPlan {
     float *T2[2], *dA, *mu, *mu_part;
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     uint16_t* xin_b; float* xin_t;   // hoisted input channels: packed bf16 operand [Kp][ncp] and its fp32 product [nb*N][ncp]
+    float* xin_f;                    // small graphs, fused AGCN kernel: scratch plane set [5][N][ncp] of the hoisted input channels
     uint16_t *Pb_e, *Pb_d;           // bf16-resident propagated planes of every AGCN call: [T][gate, update][nb][N][B*H]
     uint4* wpimg[4];                 // weight images of the streaming weight pool (enc gate, enc update, dec gate, dec update)
     size_t total;
@@ -1320,6 +1365,25 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
         P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PSb);
         P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PSb);
+    }
+    P.xin_f = nullptr;
+    {
+        // one launch per AGCN call (agcn_fused.h): bf16x3 sessions on graphs whose adjacency fits a wave's registers
+        // OPT-IN (MCRN_AGCN_FUSED=1): measured SLOWER at METR-LA (profiles/r3/README.md): a workgroup has to run both supports
+        // (and both 64-channel chunks of the decoder state) one after the other, and each is the same serial chain
+        // stage -> hop -> image -> hop that the unfused kernel runs on twice as many workgroups in parallel: 51 us for an
+        // encoder call against 15 + 17 us for the unfused pair.  Kept parity-tested (test_alternative_paths_keep_parity).
+        static const bool fused_on = getenv("MCRN_AGCN_FUSED") && atoi(getenv("MCRN_AGCN_FUSED")) == 1;
+        const bool ok = fused_on && d->precision == MCRN_BF16X3 && K == 3 && N <= 256 &&
+                        agcn_fused_ok(N, H, d->input_dim, H, P.se.ld, P.se.Cp) && agcn_fused_ok(N, H, d->input_dim, 2 * H, P.se.ld, P.se.Cp) &&
+                        agcn_fused_ok(N, Hd, od + yd, Hd, P.sd.ld, P.sd.Cp) && agcn_fused_ok(N, Hd, od + yd, 2 * Hd, P.sd.ld, P.sd.Cp) &&
+                        wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(Hd, od + yd, P.nb, Hd);
+        P.se.fused = P.sd.fused = ok;
+        if (ok) {
+            const long long ce = (long long)d->T_in * B * (P.se.Cp - H), cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
+            const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 3) & ~3LL) + 4;
+            P.xin_f = b.take<float>((size_t)5 * N * ncp);
+        }
     }
     {
         // streaming weight pool (wp_stream.h): bf16x3 sessions (fp32 planes) and the bf16 mode (bf16-resident planes when lite)
@@ -1541,7 +1605,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
         for (int i = 0; i < 4; ++i) {
             const Shp& sh_ = i < 2 ? se : sd;
             ++g_launches;
-            CK(launch_wp_img_build(P.Wf[i], sh_.Cp, sh_.H, sh_.d, P.nb, Os[i], sh_.R, P.wpimg[i], ps));
+            CK(launch_wp_img_build(P.Wf[i], sh_.Cp, sh_.H, sh_.d, P.nb, Os[i], sh_.R, P.wpimg[i], ps, sh_.fused ? 2 : 0));
         }
     // decoder input columns (:181-183): covariates, zero pad columns, go symbol = 0; the state columns of Zdec[0] are
     // written by the memory head after the encoder
@@ -1553,7 +1617,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
     CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));   // go = 0 (:182)
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));
-    if (sd.hoist && To > 1) {
+    if ((sd.hoist || sd.fused) && To > 1) {
         // the go symbol of step t+1 is labels[:, t] wherever step t is teacher-forced (:188-191): known now, so it takes
         // part in the hoisted propagation of the decoder's input channels; the other steps' go columns are zero until
         // their projection writes them (their planes are then propagated per step, below)
@@ -1581,6 +1645,9 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     if (P.bf16) {   // t-invariant part of the propagation: the input channels of every step, once per stack
         CKI(hoist_inputs(se, u, P.Zenc, P.Yenc, Ti, H, din, P.xin_b, P.xin_t, st));
         CKI(hoist_inputs(sd, u, P.Zdec, P.Ydec, To, Hd, od + yd, P.xin_b, P.xin_t, st));
+    } else if (se.fused) {
+        CKI(hoist_inputs_small(se, u, P.Zenc, P.Yenc, Ti, H, se.Cp - H, P.xin_f, st));
+        CKI(hoist_inputs_small(sd, u, P.Zdec, P.Ydec, To, Hd, sd.Cp - Hd, P.xin_f, st));
     }
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     if (wps) { we.wp_g = P.wpimg[0]; we.wp_u = P.wpimg[1]; }
@@ -1612,6 +1679,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                last ? (float*)nullptr : P.Ydec + (t + 1) * sd.ZT, (long long)sd.Cp, Hd, lab);
         // go = proj(h') was not known when the decoder's input channels were hoisted: propagate this one channel block now
         if (P.bf16 && !last && !lab) CKI(hoist_inputs(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_b, P.xin_t, st));
+        if (!P.bf16 && sd.fused && !last && !lab) CKI(hoist_inputs_small(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_f, st));
     }
     return 0;
 }

@@ -124,6 +124,24 @@ static inline size_t sfrag_uint4(int N) {
     return (size_t)NF * 2 * NF * 2 * 64;
 }
 
+// ---- one AGCN call of a small graph as one launch (agcn_fused.h) ------------------------------------------------
+enum AgcnEpi { AGF_GATE = 1, AGF_UPDATE = 2 };
+struct AgcnFP {
+    const uint4* Sf[2];       // fragment-ordered split adjacency of both supports (k_sfrag_build)
+    float* Z;                 // plane set: plane 0 = input [h | x | pad] (read), planes 1 .. 4 written (state columns)
+    long long PS, ld;         // plane stride, row stride (= B * Cp)
+    int N, B, H, d, Cp, O;
+    const uint4* Wimg;        // wp_stream.h weight image built with 2 column fragments per block
+    const float* bias;
+    int epi;                  // AGF_GATE: O = 2H ; AGF_UPDATE: O = H
+    float* out;               // GATE: zr [R][2H] ; UPDATE: hc [R][H]
+    float* out2;              // GATE: z*h (columns < H) ; UPDATE: h'   (row stride out2_ld)
+    long long out2_ld;
+    const float* hsrc;        // UPDATE: previous state h[r * hsrc_ld + c]
+    long long hsrc_ld;
+    const float* zr;          // UPDATE: the gate call's out
+};
+
 // ---- streaming d-grad (dgrad_stream.h) -----------------------------------------------------------------------
 static inline size_t wfrag_uint4(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * 64; }
 static inline bool dgrad_stream_ok(int O) { return O % 16 == 0 && O >= 16 && O <= 128; }
@@ -153,6 +171,8 @@ hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st);
 hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st);
 hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st);
 hipError_t launch_sfrag(const float* S, long long ldS, int N, int transpose, uint4* out, hipStream_t st);
+bool agcn_fused_ok(int N, int H, int d, int O, long long ld, int Cp);
+hipError_t launch_agcn_fused(const AgcnFP& p, hipStream_t st);
 hipError_t launch_dgrad_stream(DgradP p, hipStream_t st);
 // B-fragment image of Wd for the streaming d-grad (k_wfrag_build in dgrad_stream.h)
 hipError_t launch_wfrag_build(const float* W, long long ld, int rows, int K, int KS, uint4* out, long long tot, hipStream_t st);

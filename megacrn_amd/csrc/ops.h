@@ -904,6 +904,20 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
     }
     dst[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
 }
+// fp32 variant for the small graphs (bf16x3 mode: the hoisted product runs on the fused two-hop kernel of prop_small.h):
+//   dst[n][(t*B + b)*w + j] = src[t*src_t + n*ld + b*Cp + col0 + j]      columns up to ldo are zero
+__global__ void k_pack_cols_f32(const float* __restrict__ src, long long src_t, int N, long long ld, int Cp, int col0, int w, int B,
+                                int T, int ldo, float* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * ldo) return;
+    const int n = (int)(i / ldo), c = (int)(i - (long long)n * ldo);
+    float x = 0.f;
+    if (c < T * B * w) {
+        const int q = c / w, j = c - q * w, t = q / B, b = q - t * B;
+        x = src[(long long)t * src_t + (long long)n * ld + (long long)b * Cp + col0 + j];
+    }
+    dst[i] = x;
+}
 // ... and the way back: the propagated input channels, tmp[(blk*N + n)][(t*B + b)*w + j] (fp32, row stride ldt; the sum of
 // `nsplit` split-K partial products `slab` floats apart), into
 // columns [col0, col0 + w) of planes 1 + blk of the plane sets of step t - of BOTH sets of a cell (gate input Z and

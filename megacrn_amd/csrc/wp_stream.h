@@ -292,9 +292,10 @@ size_t wp_img_uint4(int H, int nbp, int O) {
     const int KSt = (nbp + 1) * (H / 16) + 1;
     return (size_t)KSt * (O / 32) * 2 * 64;
 }
-hipError_t launch_wp_img_build(const float* Wf, int Cp, int H, int d, int nbp, int O, long long R, uint4* img, hipStream_t st) {
+hipError_t launch_wp_img_build(const float* Wf, int Cp, int H, int d, int nbp, int O, long long R, uint4* img, hipStream_t st, int nbf_force) {
     if (!wp_stream_ok(H, d, nbp, O)) return hipErrorInvalidValue;
-    const int nbf = wp_pick_nbf(H, O, R);
+    if (nbf_force > 0 && O % (32 * nbf_force)) return hipErrorInvalidValue;
+    const int nbf = nbf_force > 0 ? nbf_force : wp_pick_nbf(H, O, R);
     const long long total = (long long)wp_img_uint4(H, nbp, O) / 2;          // one thread writes the hi AND the lo fragment word
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_wp_img_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Wf, Cp, H, d, nbp + 1, O, nbf, img, total);

@@ -35,7 +35,8 @@ bool wp_stream_ok(int H, int d, int nbp, int O);
 size_t wp_img_uint4(int H, int nbp, int O);                                  // uint4 elements of the weight image
 // Wf: the prepared weights [(1 + nbp) * Cp][O] (k_wprep layout: row (g, c') = g*Cp + c')
 // (R = rows of the launches that will use the image: the column-block width of the image depends on it)
-hipError_t launch_wp_img_build(const float* Wf, int Cp, int H, int d, int nbp, int O, long long R, uint4* img, hipStream_t st);
+// nbf_force > 0: that many 32-column fragments per column block (agcn_fused.h consumes blocks of 2)
+hipError_t launch_wp_img_build(const float* Wf, int Cp, int H, int d, int nbp, int O, long long R, uint4* img, hipStream_t st, int nbf_force = 0);
 hipError_t launch_wp_stream(const WpP& p, hipStream_t st);
 
 }  // namespace mcrn

@@ -857,6 +857,10 @@ def test_packed_fp32_erratum_reproducer_and_guard():
     ({"MCRN_WGRAD_STREAM": "0"}, "model_train_step or large_graph"),  # weight gradient through the tiled GEMM + column sums
     ({"MCRN_DS_MERGE": "0"}, "model_train_step or kernel_variants"),  # one adjacency-gradient launch per AGCN call
     ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
+    ({"MCRN_AGCN_FUSED": "1"}, "(model_train_step and metrla) or full_size_metrla"),   # one launch per AGCN call (agcn_fused.h, opt-in)
+    ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 300)"),   # tiled weight pool
+    ({"MCRN_HOIST": "0"}, "bf16_mode_train and 300"),                # bf16 mode without hoisting (all B*Cp columns per step)
+    ({"MCRN_BF16_PLANES": "0"}, "bf16_mode_train and 300"),          # hoisted propagation into fp32 planes (no bf16-resident planes)
 ])
 def test_alternative_paths_keep_parity(env, select):
     import subprocess
