@@ -341,13 +341,14 @@ static const int NSLAB_W_GEMM = 64;   // ... slabs the tiled-GEMM fallback split
 static const int NSLAB_T = 256;   // split-K slabs of the tiny-output, very-long-K products (dWq, dMem, dWp): one tile, so K must fill the chip
 static const int NSLAB_E = 16;    // split-K slabs of dE1 / dE2 (N x D outputs, K = N)
 
+static const int MCRN_MAX_CHEB_K = 8;     // model/MegaCRN.py:21-22 recurses for any cheb_k >= 2; 2 and 3 have the fused fast paths
 static inline bool ds_small_enabled() {
     static const bool on = !(getenv("MCRN_DS_SMALL") && atoi(getenv("MCRN_DS_SMALL")) == 0);   // default on: 9.9 vs 10.7 ms/step at METR-LA
     return on;
 }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool use_prop_small(const Sup& u, const Shp& s) {
-    return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && prop_small_ok(s.N, s.ld, (int)s.ld);
+    return g_precision == MCRN_BF16X3 && s.K <= 3 && u.Sf[0] && u.Stf[0] && prop_small_ok(s.N, s.ld, (int)s.ld);
 }
 // fused two-hop kernels (cheb_k = 3): also 256 < N <= 352, where the other adjacency-stationary kernels do not reach
 static inline bool use_prop2(const Sup& u, const Shp& s) {
@@ -652,11 +653,12 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16
     // algorithmic flops per launch: 2 supports x 2*N^2*B*C with the TRUE channel count (no pad)
     p.alg_flops = 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
     CKI(gemm(p, true, false, 0, ROLE_PROP, st));
-    if (s.K == 3) {   // x2 = 2 S x1 - x0
+    for (int k = 2; k < s.K; ++k) {   // x_k = 2 S x_{k-1} - x_{k-2}   (model/MegaCRN.py:21-22 as a feature recursion)
         for (int b = 0; b < 2; ++b) {
-            p.B[b] = Z + (1 + 2 * b) * s.PS;
-            p.C[b] = Z + (2 + 2 * b) * s.PS;
-            p.Cin[b] = Z;
+            const long long g1 = 1 + (long long)b * (s.K - 1);          // plane of x_1 of support b; x_k sits at g1 + k - 1
+            p.B[b] = Z + (g1 + k - 2) * s.PS;
+            p.C[b] = Z + (g1 + k - 1) * s.PS;
+            p.Cin[b] = k == 2 ? Z : Z + (g1 + k - 3) * s.PS;
         }
         p.alpha = 2.f; p.beta = -1.f;
         CKI(gemm(p, true, false, 0, ROLE_PROP, st));
@@ -677,12 +679,60 @@ static int wp_fwd(const Shp& s, const float* Z, const float* Wf, int O, GemmP ep
     return gemm(p, true, false, 0, ROLE_WP, st);
 }
 
+// ---- AGCN backward for cheb_k > 3: the Chebyshev recursion differentiated step by step (oracle: agcn_bwd) on the tiled GEMM.
+//   raw plane gradients d_k = dY W_k^T (Wd unfolded), then per support, k = K-1 .. 2:
+//     dS += 2 d_k x_{k-1}^T ; d_{k-1} += 2 S^T d_k ; d_{k-2} -= d_k        and finally  dS += d_1 x_0^T ; d_0 += S^T d_1
+static int agcn_bwd_general(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd, const float* X, float* dP,
+                            hipStream_t st, const uint4* imgd) {
+    {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
+        GemmP p = gp();
+        p.M = (int)s.R; p.N = s.G * s.Cp; p.K = O;
+        p.A[0] = dY; p.am = plain(O); p.ak = plain(1);
+        p.B[0] = Wd; p.bk = plain(1); p.bn = plain(O);
+        p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
+        (void)imgd;
+        CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
+    }
+    auto ds_acc = [&](int b, const float* dk, const float* xk, float alpha) -> int {   // dS_b += alpha dk xk^T, split-K slabs
+        GemmP p = gp();
+        p.M = s.N; p.N = s.N; p.K = (int)s.ld;
+        p.A[0] = dk; p.am = plain(s.ld); p.ak = plain(1);
+        p.B[0] = xk; p.bn = plain(s.ld); p.bk = plain(1);
+        p.C[0] = u.dS + (long long)b * u.sup_stride; p.Cin[0] = p.C[0]; p.cm = plain(u.ldS); p.cn = plain(1);
+        p.alpha = alpha; p.beta = 1.f; p.slab = u.slab;
+        return gemm(p, true, true, u.nslab, ROLE_DS, st);
+    };
+    auto st_acc = [&](int b, const float* src, float* dst, float alpha) -> int {       // dst += alpha S_b^T src
+        GemmP p = gp();
+        p.M = s.N; p.N = (int)s.ld; p.K = s.N;
+        p.A[0] = u.St[b]; p.am = plain(u.ldS); p.ak = plain(1);
+        p.B[0] = src; p.bk = plain(s.ld); p.bn = plain(1);
+        p.C[0] = dst; p.Cin[0] = dst; p.cm = plain(s.ld); p.cn = plain(1);
+        p.alpha = alpha; p.beta = 1.f;
+        return gemm(p, true, false, 0, ROLE_PROPT, st);
+    };
+    for (int b = 0; b < 2; ++b) {
+        const long long g1 = 1 + (long long)b * (s.K - 1);
+        auto plane = [&](float* base, int k) { return k == 0 ? base : base + (g1 + k - 1) * s.PS; };
+        for (int k = s.K - 1; k >= 2; --k) {
+            float* dk = plane(dP, k);
+            CKI(ds_acc(b, dk, plane(const_cast<float*>(X), k - 1), 2.f));
+            CKI(st_acc(b, dk, plane(dP, k - 1), 2.f));
+            LAUNCH(k_axpy, dim3(cdiv(s.PS, 256)), dim3(256), 0, st, plane(dP, k - 2), (const float*)dk, -1.f, s.PS);
+        }
+        CKI(ds_acc(b, plane(dP, 1), X, 1.f));
+        CKI(st_acc(b, plane(dP, 1), dP, 1.f));
+    }
+    return 0;
+}
+
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
                          float* dT = nullptr, int* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
                          bool cell_ds_last = true) {
     if (used_dT) *used_dT = 0;
+    if (s.K > 3) return agcn_bwd_general(s, u, dY, O, Wd, X, dP, st, imgd);
     bool dgrad_wrote_bf16 = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
@@ -1187,7 +1237,7 @@ static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long l
 static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st, uint4* imgf = nullptr,
                  uint4* imgd = nullptr) {
     long long tot = (long long)s.G * s.Cp * O;
-    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, g_prop_bf16 ? 0 : 1);
+    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, (g_prop_bf16 || s.K != 3) ? 0 : 1);
     if (imgf && g_precision == MCRN_BF16X3) {
         const int Kp = s.G * s.Cp;
         {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
@@ -1257,7 +1307,8 @@ static int check_dims(const mcrn_dims_t* d) {
     if (d->B < 1 || d->N < 1 || d->T_in < 1 || d->T_out < 1 || d->input_dim < 1 || d->output_dim < 1 ||
         d->ycov_dim < 0 || d->H < 1 || d->mem_num < 1 || d->mem_dim < 1)
         FAIL("mcrn_dims: all sizes must be >= 1");
-    if (d->cheb_k != 2 && d->cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", d->cheb_k);
+    if (d->cheb_k < 2 || d->cheb_k > MCRN_MAX_CHEB_K) FAIL("cheb_k must be in 2 .. %d (got %d; cheb_k = 1 is broken in the reference too)", MCRN_MAX_CHEB_K, d->cheb_k);
+    if (d->precision == MCRN_BF16 && d->cheb_k > 3) FAIL("the bf16 mode builds the Chebyshev matrices [S, 2SS - I]: cheb_k 2 or 3 (got %d)", d->cheb_k);
     if (d->precision != MCRN_F32 && d->precision != MCRN_BF16X3 && d->precision != MCRN_BF16)
         FAIL("unsupported precision %d", d->precision);
     return 0;
@@ -2180,7 +2231,7 @@ int mcrn_supports_backward(int N, int M, int D, const float* We1, const float* W
 
 // ---- AGCN ---------------------------------------------------------------------------------------
 size_t mcrn_agcn_workspace_bytes(int B, int N, int C, int O, int cheb_k) {
-    if (B < 1 || N < 1 || C < 1 || O < 1 || (cheb_k != 2 && cheb_k != 3)) return 0;
+    if (B < 1 || N < 1 || C < 1 || O < 1 || (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K)) return 0;
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, nullptr, P);
     return P.total;
@@ -2188,7 +2239,7 @@ size_t mcrn_agcn_workspace_bytes(int B, int N, int C, int O, int cheb_k) {
 int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, const float* s1, const float* s2,
                       const float* W, const float* bias, void* ws, size_t ws_bytes, float* y, void* stream) {
     ENTER();
-    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K) FAIL("cheb_k must be in 2 .. %d (got %d)", MCRN_MAX_CHEB_K, cheb_k);
     if (B < 1 || N < 1 || C < 1 || O < 1) FAIL("agcn: bad sizes");
     if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -2210,7 +2261,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
                        const float* W, void* ws, size_t ws_bytes, float* dx, float* ds1, float* ds2, float* dW,
                        float* db, void* stream) {
     ENTER();
-    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K) FAIL("cheb_k must be in 2 .. %d (got %d)", MCRN_MAX_CHEB_K, cheb_k);
     if (ws_bytes < mcrn_agcn_workspace_bytes(B, N, C, O, cheb_k)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
     AgcnPlan P;
@@ -2235,7 +2286,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
 
 // ---- cell ---------------------------------------------------------------------------------------
 size_t mcrn_cell_workspace_bytes(int B, int N, int din, int H, int cheb_k) {
-    if (B < 1 || N < 1 || din < 0 || H < 1 || (cheb_k != 2 && cheb_k != 3)) return 0;
+    if (B < 1 || N < 1 || din < 0 || H < 1 || (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K)) return 0;
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, nullptr, P);
     return P.total;
@@ -2244,7 +2295,7 @@ int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, 
                       const float* s2, const float* gate_w, const float* gate_b, const float* update_w,
                       const float* update_b, void* ws, size_t ws_bytes, float* hn, void* stream) {
     ENTER();
-    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K) FAIL("cheb_k must be in 2 .. %d (got %d)", MCRN_MAX_CHEB_K, cheb_k);
     if (B < 1 || N < 1 || din < 0 || H < 1) FAIL("cell: bad sizes");
     if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -2270,7 +2321,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
                        void* stream) {
     ENTER();
     (void)gate_w; (void)update_w;
-    if (cheb_k != 2 && cheb_k != 3) FAIL("cheb_k must be 2 or 3 (got %d)", cheb_k);
+    if (cheb_k < 2 || cheb_k > MCRN_MAX_CHEB_K) FAIL("cheb_k must be in 2 .. %d (got %d)", MCRN_MAX_CHEB_K, cheb_k);
     if (ws_bytes < mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)) FAIL("workspace too small");
     hipStream_t st = (hipStream_t)stream;
     CellPlan P;

@@ -612,6 +612,12 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
     dacc[i] = g * rr;
 }
 
+// dst += a * src   (plane-wise step of the Chebyshev recursion backward for cheb_k > 3: d_{k-2} -= d_k)
+__global__ void k_axpy(float* __restrict__ dst, const float* __restrict__ src, float a, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += a * src[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // deterministic column sums:  out[c] (+)= sum_r w[r]*X[r*ld + c]   (w nullable), two stages
 // ---------------------------------------------------------------------------------------------

@@ -108,7 +108,7 @@ class _AGCNFn(torch.autograd.Function):
         O = W.shape[1]
         nb = lib.mcrn_agcn_workspace_bytes(B, N, Cc, O, cheb_k)
         if nb == 0:
-            raise ValueError(f"AGCN: unsupported sizes / cheb_k={cheb_k} (supported: 2, 3)")
+            raise ValueError(f"AGCN: unsupported sizes / cheb_k={cheb_k} (supported: 2 .. 8)")
         ws = _pool.take(nb, x.device)
         y = torch.empty(B, N, O, device=x.device)
         check(lib.mcrn_agcn_forward(B, N, Cc, O, cheb_k, _p(x), _p(s1), _p(s2), _p(W), _p(b), _p(ws), nb, _p(y),
@@ -145,7 +145,7 @@ class _CellFn(torch.autograd.Function):
         H = h.shape[2]
         nb = lib.mcrn_cell_workspace_bytes(B, N, din, H, cheb_k)
         if nb == 0:
-            raise ValueError(f"AGCRNCell: unsupported sizes / cheb_k={cheb_k} (supported: 2, 3)")
+            raise ValueError(f"AGCRNCell: unsupported sizes / cheb_k={cheb_k} (supported: 2 .. 8)")
         ws = _pool.take(nb, x.device)
         hn = torch.empty(B, N, H, device=x.device)
         check(lib.mcrn_cell_forward(B, N, din, H, cheb_k, _p(x), _p(h), _p(s1), _p(s2), _p(gw), _p(gb), _p(uw),

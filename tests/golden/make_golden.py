@@ -196,9 +196,13 @@ def run_ops():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cheb4":      # (adds the one case without rewriting the others)
+        run_case("cheb4", B=2, N=19, T_in=3, T_out=3, H=8, M=5, D=8, cheb_k=4, seed=6)
+        sys.exit(0)
     run_ops()
     run_case("tiny", B=3, N=13, T_in=4, T_out=4, H=8, M=5, D=8, seed=1)
     run_case("odd", B=2, N=37, T_in=3, T_out=5, H=12, M=7, D=10, seed=2)
     run_case("layers2", B=2, N=11, T_in=3, T_out=3, H=8, M=5, D=8, num_layers=2, seed=3)
     run_case("cheb2", B=2, N=17, T_in=3, T_out=3, H=8, M=5, D=8, cheb_k=2, seed=4)
     run_case("metrla", B=2, N=207, T_in=12, T_out=12, H=64, M=20, D=64, seed=5, dtypes=("f32",), traj=False, slim=True)
+    run_case("cheb4", B=2, N=19, T_in=3, T_out=3, H=8, M=5, D=8, cheb_k=4, seed=6)     # --max_diffusion_step 4 (:21-22 recurse twice)

@@ -145,7 +145,7 @@ def build(amd, P, m):
     return model.cuda()
 
 
-CASES = ["tiny", "odd", "cheb2", "layers2", "metrla"]
+CASES = ["tiny", "odd", "cheb2", "layers2", "metrla", "cheb4"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -305,7 +305,9 @@ def test_trainer_matches_oracle_trajectory(amd):
 
 def test_errors_are_loud(amd):
     with pytest.raises((ValueError, RuntimeError)):
-        amd.AGCN(4, 4, 4).cuda()(torch.randn(2, 5, 4, device="cuda"), [torch.eye(5, device="cuda")] * 2)
+        amd.AGCN(4, 4, 1).cuda()(torch.randn(2, 5, 4, device="cuda"), [torch.eye(5, device="cuda")] * 2)   # cheb_k = 1: broken in the reference too
+    with pytest.raises((ValueError, RuntimeError)):
+        amd.AGCN(4, 4, 9).cuda()(torch.randn(2, 5, 4, device="cuda"), [torch.eye(5, device="cuda")] * 2)   # beyond the supported 2 .. 8
     with pytest.raises(RuntimeError):
         amd.MegaCRN(5, 1, 1, 2, 4)(torch.randn(1, 2, 5, 1), torch.randn(1, 2, 5, 1))
 
@@ -858,9 +860,9 @@ def test_packed_fp32_erratum_reproducer_and_guard():
     ({"MCRN_DS_MERGE": "0"}, "model_train_step or kernel_variants"),  # one adjacency-gradient launch per AGCN call
     ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
     ({"MCRN_AGCN_FUSED": "1"}, "(model_train_step and metrla) or full_size_metrla"),   # one launch per AGCN call (agcn_fused.h, opt-in)
-    ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 300)"),   # tiled weight pool
-    ({"MCRN_HOIST": "0"}, "bf16_mode_train and 300"),                # bf16 mode without hoisting (all B*Cp columns per step)
-    ({"MCRN_BF16_PLANES": "0"}, "bf16_mode_train and 300"),          # hoisted propagation into fp32 planes (no bf16-resident planes)
+    ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 1843)"),   # tiled weight pool
+    ({"MCRN_HOIST": "0"}, "bf16_mode_train and 1843"),               # bf16 mode without hoisting (all B*Cp columns per step)
+    ({"MCRN_BF16_PLANES": "0"}, "bf16_mode_train and 1843"),         # hoisted propagation into fp32 planes (no bf16-resident planes)
 ])
 def test_alternative_paths_keep_parity(env, select):
     import subprocess

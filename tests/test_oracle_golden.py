@@ -8,7 +8,7 @@ from helpers import load_case, relerr, SC_MEAN, SC_STD
 
 CASES = [("tiny", "f32"), ("tiny", "f64"), ("odd", "f32"), ("odd", "f64"),
          ("layers2", "f32"), ("layers2", "f64"), ("cheb2", "f32"), ("cheb2", "f64"),
-         ("metrla", "f32")]
+         ("metrla", "f32"), ("cheb4", "f32"), ("cheb4", "f64")]
 TOL = {"f32": 2e-5, "f64": 1e-11}
 GTOL = {"f32": 2e-4, "f64": 1e-10}   # gradients: fp32 accumulation-order noise through 2T cells
 
