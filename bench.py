@@ -93,8 +93,12 @@ def propagation_alg_bytes(cfg, B, dtype):
     step like the flops (read the supports once, the input plane once, write the propagated planes)."""
     N, H, D, K = cfg["N"], cfg["H"], cfg["D"], 3
     out = []
-    for C in (1 + H, 2 + H + D):
-        if dtype == "bf16":       # stacked bf16 adjacency (2(K-1) blocks), bf16 input plane, fp32 output planes
+    for C, Hs in ((1 + H, H), (2 + H + D, H + D)):
+        if dtype == "bf16" and Hs in (32, 64, 128):
+            # hoisted bf16 mode (DESIGN.md section 3): stacked bf16 adjacency (2(K-1) blocks), the bf16 state block (Hs channels;
+            # the input channels are propagated once per stack), bf16-resident output planes
+            out.append(2 * (K - 1) * N * N * 2 + N * B * Hs * 2 + 2 * (K - 1) * N * B * Hs * 2)
+        elif dtype == "bf16":     # stacked bf16 adjacency, bf16 input plane, fp32 output planes
             out.append(2 * (K - 1) * N * N * 2 + N * B * C * 2 + 2 * (K - 1) * N * B * C * 4)
         else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
             out.append(2 * N * N * 4 + N * B * C * 4 + 2 * (K - 1) * N * B * C * 4)

@@ -24,8 +24,9 @@
  *  - Process model: ONE host thread and ONE device per process (one process per GPU).  The library keeps a
  *    process-wide helper stream, tile cache and profiler; every compute entry point refuses (MCRN_EINVAL) a call
  *    that arrives while another host thread is inside the library, or on a different device than the first call.
- *  - Supported: cheb_k in {2,3}; any B,N,H,input/output/ycov dims >= 1;
- *    num_layers == 1 in the fused model entry points (multi-layer models are
+ *  - Supported: cheb_k in 2 .. 8 (model/MegaCRN.py:21-22 recurses for any cheb_k >= 2; 2 and 3 have the fused fast
+ *    paths, larger orders run the recursion step by step on the tiled GEMM; MCRN_BF16: 2 or 3); any B,N,H,
+ *    input/output/ycov dims >= 1; num_layers == 1 in the fused model entry points (multi-layer models are
  *    composed from mcrn_cell_* by the host module).
  */
 #ifndef MEGACRN_HIP_H
@@ -45,8 +46,11 @@ extern "C" {
                           accumulate: ~1e-5 relative error, 5.3x the MFMA rate of MCRN_F32 (default) */
 #define MCRN_BF16 2    /* fused model entry points only: the K-hop propagation, its transpose and the adjacency
                           gradient run on bf16-RESIDENT operands (one bf16 MFMA per product, fp32 accumulate; the
-                          Chebyshev terms as the reference's own matrices [S, 2SS-I], model/MegaCRN.py:20-22),
-                          everything else as MCRN_BF16X3.  Stated tolerance 2e-2 (tests); the large-graph mode. */
+                          Chebyshev terms as the reference's own matrices [S, 2SS-I], model/MegaCRN.py:20-22).  With
+                          rnn_units in {32, 64, 128} (H + mem_dim for the decoder likewise) the per-step propagation
+                          covers the state channels only (the input channels of every step are propagated once per
+                          stack) and writes bf16-resident planes that a streaming weight-pool kernel consumes; every
+                          other contraction as MCRN_BF16X3.  Stated tolerance 2e-2 (tests); the large-graph mode. */
 
 typedef struct mcrn_dims {
     int B;          /* batch */
@@ -59,7 +63,7 @@ typedef struct mcrn_dims {
     int H;          /* rnn_units */
     int mem_num;    /* M */
     int mem_dim;    /* D */
-    int cheb_k;     /* 2 or 3 */
+    int cheb_k;     /* 2 .. 8 (MCRN_BF16: 2 or 3) */
     int precision;  /* MCRN_F32, MCRN_BF16X3 or MCRN_BF16 */
 } mcrn_dims_t;
 

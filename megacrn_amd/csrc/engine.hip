@@ -527,7 +527,7 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     // splits the launcher really makes (bf16_split_plan) for a K tile of 64 and of 32: the consumer below must know the count
     // whatever tile configuration the tuner picks, so a request that the two depths would round differently is not split
     auto eff = [&](int bk) { const int kt = cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
-    if (eff(64) != eff(32)) nsplit = 1;
+    if (eff(64) != eff(32) || bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;    // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64);
     p.slab = (long long)p.M * ncp;
     CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));

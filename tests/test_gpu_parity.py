@@ -750,12 +750,14 @@ def test_bf16_mode_full_size_properties(name):
     x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
     ycov = rng.random((B, T, N, 1)).astype(np.float32)
     perm = rng.permutation(B)
-    # every sample's arithmetic is independent of its position and of its neighbours.  In the tile configurations the tuner
-    # chooses, a column's K loop runs in the same order wherever the column sits: 2e-5.  The opt-in stream-K configurations
-    # (MCRN_BF16_CFG=10..12, exercised by test_alternative_paths_keep_parity) cut K at tile-dependent points, the state
-    # then differs in its last fp32 bit, and that can flip the bf16 rounding (2^-9 relative) of an element of the next
-    # step's operand: position independence holds to the mode's arithmetic, 5e-4.
-    ptol = 5e-4 if os.environ.get("MCRN_BF16_CFG") else 2e-5
+    # every sample's arithmetic is independent of its position and of its neighbours - to the mode's arithmetic: wherever a
+    # K loop is cut at a point that depends on the shape (the stream-K configurations MCRN_BF16_CFG=10..12; the split-K
+    # hoisted product below), a value differs in its last fp32 bit, and that can flip the bf16 rounding (2^-9 relative)
+    # of an element of the next step's operand (the re-run on the same shape stays bit-identical).
+    # The hoisted product of the input channels (one launch per stack) is split over K according to ITS width, which
+    # depends on the batch: a prefix of the batch then sees input planes that differ in their last fp32 bit.  Bound 1e-3
+    # (measured up to 5.1e-4 under stream-K), a twentieth of the mode's stated tolerance.
+    ptol = 1e-3
     with torch.no_grad():
         o1 = [t.clone() for t in model(dev(x), dev(ycov))]
         o2 = model(dev(x), dev(ycov))

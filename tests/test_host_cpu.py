@@ -31,9 +31,14 @@ def test_workspace_sizing_and_validation():
     d = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 3, 0)
     nb = lib.mcrn_model_workspace_bytes(C.byref(d))
     assert 1 << 28 < nb < 1 << 33          # ~1.5 GB of saved activations at METR-LA B=64
-    d2 = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 4, 0)   # cheb_k=4 unsupported
-    assert lib.mcrn_model_workspace_bytes(C.byref(d2)) == 0
-    assert b"cheb_k" in lib.mcrn_last_error()
+    d4 = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 4, 0)   # cheb_k = 4: two more planes per support than cheb_k = 3
+    assert lib.mcrn_model_workspace_bytes(C.byref(d4)) > nb
+    for bad in (1, 9):                                        # cheb_k = 1 is broken in the reference too; 2 .. 8 supported
+        d2 = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, bad, 0)
+        assert lib.mcrn_model_workspace_bytes(C.byref(d2)) == 0
+        assert b"cheb_k" in lib.mcrn_last_error()
+    d3 = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 4, 2)    # the bf16 mode builds [S, 2SS - I]: cheb_k 2 or 3 only
+    assert lib.mcrn_model_workspace_bytes(C.byref(d3)) == 0 and b"bf16" in lib.mcrn_last_error()
     assert lib.mcrn_cell_workspace_bytes(3, 13, 2, 8, 3) > 0
     assert lib.mcrn_agcn_workspace_bytes(3, 13, 9, 16, 1) == 0
 

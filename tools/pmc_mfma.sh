@@ -29,10 +29,18 @@ for n, disp in rows.items():
         continue
     out.append((mf, n, k, mf / k, busy / k, agg.get("GRBM_GUI_ACTIVE", 0.0) / k, agg.get("SQ_WAVE_CYCLES", 0.0) / k,
                 agg.get("SQ_WAIT_ANY", 0.0) / k, agg.get("SQ_WAIT_INST_ANY", 0.0) / k))
-lines = ["kernel | dispatches averaged | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | MFMA busy / (GUI_ACTIVE x 256 CU x 4 SIMD) | WAIT_ANY/WAVE_CYCLES | WAIT_INST_ANY/WAVE_CYCLES"]
-for mf, n, k, mfa, busy, gui, wc, wa, wi in sorted(out, reverse=True)[:24]:
-    util = mfa / (gui * 1024.0) if gui else 0.0
-    lines.append(f"{n[:72]:72s} | {k:3d} | {mfa:14.0f} | {busy:12.0f} | {gui:9.0f} | {100 * util:5.1f} % | {wa / wc if wc else 0:5.2f} | {wi / wc if wc else 0:5.2f}")
+lines = ["MFMA utilisation of the in-model launches (last <= 48 dispatches of each kernel; counters are chip totals per dispatch):",
+         "  util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs)   [SQ_BUSY_CYCLES sums the busy cycles of the 32 SEs:",
+         "  SQ_BUSY_CYCLES / 32 is the kernel's duration in shader cycles; MFMA_BUSY counts 32 cycles per v_mfma_f32_32x32x16_bf16 per SIMD]",
+         "kernel | dispatches averaged | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | duration (cycles) | MFMA util | WAIT_ANY/WAVE_CYCLES | WAIT_INST_ANY/WAVE_CYCLES"]
+for mf, n, k, mfa, busy, gui, wc, wa, wi in sorted(out, reverse=True):
+    if k < 40 and "gemm_bf16" in n:
+        continue                                   # tile configurations only the autotuner launched
+    dur = busy / 32.0
+    util = mfa / (dur * 1024.0) if dur else 0.0
+    lines.append(f"{n[:72]:72s} | {k:3d} | {mfa:14.0f} | {busy:12.0f} | {dur:9.0f} | {100 * util:5.1f} % | {wa / wc if wc else 0:5.2f} | {wi / wc if wc else 0:5.2f}")
+    if len(lines) > 30:
+        break
 open(f"{root}/mfma_{tag}.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
