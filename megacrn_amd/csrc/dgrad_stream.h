@@ -143,7 +143,37 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
             const int g = n / p.Cp;
             int cp = p.Cp;
             asm volatile("" : "+s"(cp));                               // row offsets stay scalar multiples, not 16 live VGPR pairs
-            if (p.dPb && g > 0) {                                      // bf16 gradient plane (same row / column indexing)
+            if (p.dPb && g > 0 && p.H > 0) {                           // hoisted backward: packed state channels / stack-wide input operand
+                const int cc = n - g * p.Cp;
+                if (cc < p.H) {
+                    unsigned short* __restrict__ c = p.dPb + (long long)(g - 1) * p.PSb + cc + r0 * p.H;
+                    int hh = p.H;
+                    asm volatile("" : "+s"(hh));
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int dr = (v & 3) + 8 * (v >> 2);
+                        unsigned u = __float_as_uint(acc[v] + acx[v]);
+                        u += 0x7FFFu + ((u >> 16) & 1u);
+                        if (rows_in || r0 + dr < p.R) c[dr * hh] = (unsigned short)(u >> 16);
+                    }
+                } else if (cc < p.H + p.d && p.dPin) {
+                    // row r = n * B + b -> element (n, in_col0 + b * d + j): one division, then the 28 row steps by carry
+                    unsigned nn = (unsigned)r0 / (unsigned)p.B, bb = (unsigned)r0 - nn * (unsigned)p.B;
+                    unsigned short* __restrict__ c = p.dPin + (long long)(g - 1) * p.in_plane + p.in_col0 + (cc - p.H);
+#pragma unroll
+                    for (int dr = 0; dr < 28; ++dr) {
+                        if ((dr & 4) == 0) {
+                            const int v = (dr & 3) + 4 * (dr >> 3);
+                            if (rows_in || r0 + dr < p.R) {
+                                unsigned u = __float_as_uint(acc[v] + acx[v]);
+                                u += 0x7FFFu + ((u >> 16) & 1u);
+                                c[(long long)nn * p.kin + bb * p.d] = (unsigned short)(u >> 16);
+                            }
+                        }
+                        if (++bb == (unsigned)p.B) { bb = 0; ++nn; }
+                    }
+                }
+            } else if (p.dPb && g > 0) {                               // bf16 gradient plane (same row / column indexing)
                 unsigned short* __restrict__ c = p.dPb + (long long)(g - 1) * p.PSb + (n - g * p.Cp) + r0 * p.Cp;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {

@@ -286,6 +286,7 @@ struct Shp {   // one AGCN / cell geometry
                                   // the input channels of every step are propagated once per stack
     bool fused;                   // bf16x3, N <= 256, cheb_k = 3: one launch per AGCN call (agcn_fused.h); the input (and pad)
                                   // channels of every step are propagated once per stack here too
+    long long PSbh;               // Kp * ldh: one packed bf16 [Kp][B*H] matrix
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
 };
@@ -304,6 +305,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     static const bool hoist_off = getenv("MCRN_HOIST") && atoi(getenv("MCRN_HOIST")) == 0;
     s.hoist = bf16_rows && !hoist_off && (H % 32) == 0 && d > 0;
     s.ldh = (long long)B * H;
+    s.PSbh = (long long)s.Kp * s.ldh;
     s.fused = false;              // (set by plan_model: needs both output widths of the cell and the session precision)
     static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
     s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
@@ -473,10 +475,17 @@ static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, ui
 // MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
 //   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
 // T2(S) = 2 S S - I is the reference's own matrix form (model/MegaCRN.py:20-22), built once per step.
-static int pack_cols_bf16(const float* src, long long src_t, const Shp& s, int col0, int w, int T, int ldo, uint16_t* dst, hipStream_t st) {
-    const long long n = (long long)s.Kp * (ldo / 8);
-    LAUNCH(k_pack_cols_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, src, src_t, s.N, s.ld, s.Cp, col0, w, s.B, T, s.Kp, ldo,
-           reinterpret_cast<uint4*>(dst));
+struct PackX {                    // optional arguments of k_pack_cols_bf16 (see ops.h)
+    int ny = 1; long long src_y = 0, dst_y = 0;                    // planes (grid.y), strides: floats / uint4
+    const float* mu = nullptr; long long mu_t = 0, mu_y = 0; float inv_rows = 0.f;
+    int coff = 0, ncw = 0, tmul = 1, toff = 0, rows = -1;          // rows: destination rows (default Kp, zero beyond N)
+};
+static int pack_cols_bf16(const float* src, long long src_t, const Shp& s, int col0, int w, int T, int ldo, uint16_t* dst, hipStream_t st,
+                          const PackX& x = PackX()) {
+    const int rows = x.rows < 0 ? s.Kp : x.rows;
+    const long long n = (long long)rows * ((x.ncw > 0 ? x.ncw : ldo) / 8);
+    LAUNCH(k_pack_cols_bf16, dim3(cdiv(n, 256), x.ny), dim3(256), 0, st, src, src_t, s.N, s.ld, s.Cp, col0, w, s.B, T, rows, ldo,
+           reinterpret_cast<uint4*>(dst), x.src_y, x.dst_y, x.mu, x.mu_t, x.mu_y, x.inv_rows, x.coff, x.ncw, x.tmul, x.toff);
     return 0;
 }
 static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, uint16_t* x0c, hipStream_t st,
@@ -565,16 +574,20 @@ static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, in
 static const int PROPT_MAX_X = 3;                       // extra partial planes behind dT (K splits 1 .. 3)
 struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
 static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
-static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, int* used_dT, hipStream_t st) {
+// hoisted (the packed operand dPb = [nb][Kp][B*H]): only the state channels of plane 0 receive a propagated gradient here;
+// the input channels' share (needed for the go symbol of a step that was not teacher-forced) is go_grad_bf16 below
+static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, int* used_dT, hipStream_t st,
+                         bool hoisted = false) {
     Bf16GemmP p = bgp(u);
     p.A = u.STstk; p.am = rm_plain((long long)u.nb * u.Kp); p.M = s.N;
     p.B = dPb; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PSb;
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
+    if (hoisted) { p.ldb = s.ldh; p.N = (int)s.ldh; p.b_seg = s.PSbh; p.cn_inner = s.H; p.cn_hi = s.Cp; }
     int nsplit = 1;
     static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 0;   // 0: tuned (2 .. 4)
-    const double alg = (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
-    if (dT && used_dT && split_env != 1 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(s.ld, 128) < 512) {
+    const double alg = (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * (hoisted ? s.H : s.C);
+    if (dT && used_dT && split_env != 1 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(p.N, 128) < 512) {
         // The output is only N x B*Cp while K is nb*N deep: K is split, split 0 accumulates into plane 0, the others land in
         // the extra planes dT .. that the element-wise consumers of plane 0 add in a fixed order (no reduction pass, one
         // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
@@ -609,6 +622,45 @@ static int ds_bf16(const Shp& s, const Sup& u, const uint16_t* dPb_all, const ui
     p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS);
     if (accumulate) { p.Cin = dA; p.beta = 1.f; }
     return bf16_gemm(p, false, 1, ROLE_DS, (double)ncalls * u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, st);
+}
+
+// hoisted backward: the same product on the packed state-channel operands (K = B*H per call) ...
+static int ds_bf16_h(const Shp& s, const Sup& u, const uint16_t* dPbh_all, const uint16_t* x0ch_all, int ncalls, float* dA,
+                     long long ldS, bool accumulate, hipStream_t st) {
+    Bf16GemmP p = bgp(u);
+    p.A = dPbh_all; p.am = rm_two(s.N, s.PSbh, s.ldh); p.M = u.nb * s.N;
+    p.B = x0ch_all; p.bm = rm_plain(s.ldh); p.N = s.N;
+    p.nseg = ncalls; p.seg_len = (int)s.ldh; p.a_seg = (long long)u.nb * s.PSbh; p.b_seg = s.PSbh;
+    p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS);
+    if (accumulate) { p.Cin = dA; p.beta = 1.f; }
+    return bf16_gemm(p, false, 1, ROLE_DS, (double)ncalls * u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.H, st);
+}
+// ... plus the input channels of every call as ONE narrow product:  dA[b] += dPin[b] (N x kcols) x xin_c^T (N x kcols)
+static int ds_bf16_in(const Shp& s, const Sup& u, const uint16_t* dPin, const uint16_t* xin_c, long long kin, int kcols, float* dA,
+                      long long ldS, hipStream_t st) {
+    Bf16GemmP p = bgp(u);
+    p.A = dPin; p.am = rm_plain(kin); p.M = u.nb * s.N;
+    p.B = xin_c; p.bm = rm_plain(kin); p.N = s.N;
+    p.nseg = 1; p.seg_len = kcols;
+    p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS); p.Cin = dA; p.beta = 1.f;
+    return bf16_gemm(p, false, 1, ROLE_DS, (double)u.nb * 2.0 * (double)s.N * s.N * (double)kcols, st);
+}
+// hoisted backward, a decoder cell whose go symbol was the projection of the previous step (not teacher-forced): the input
+// channels of its planes 1 .. nb carry gradient for that symbol,  d go += sum_g T_g^T dP_g[:, input columns] ; both calls of the
+// cell (adjacent column blocks of the stack-wide operand dPin) in one product, added to the go columns of the two planes 0
+static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long long kin, int call0, float* tmp, float* dQ0, float* dP0,
+                        int od, hipStream_t st) {
+    const int bw = s.B * s.d;                                       // columns of one call
+    Bf16GemmP p = bgp(u);
+    p.A = u.STstk; p.am = rm_plain((long long)u.nb * u.Kp); p.M = s.N;
+    p.B = dPin + (long long)call0 * bw; p.ldb = kin; p.N = 2 * bw;
+    p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = (long long)s.N * kin;
+    p.C = tmp; p.cm = rm_plain(2 * bw);
+    CKI(bf16_gemm(p, true, 1, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * 2.0 * bw, st));
+    const long long tot = (long long)s.N * s.B * od;
+    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, 0, s.N, s.B, s.d, od, dQ0, s.ld, s.Cp, s.H);
+    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, bw, s.N, s.B, s.d, od, dP0, s.ld, s.Cp, s.H);
+    return 0;
 }
 
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
@@ -730,7 +782,8 @@ static int agcn_bwd_general(const Shp& s, const Sup& u, const float* dY, int O, 
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
                          float* dT = nullptr, int* used_dT = nullptr, uint16_t* dPb = nullptr, DsP* cell_ds = nullptr,
-                         bool cell_ds_last = true) {
+                         bool cell_ds_last = true, uint16_t* dPin = nullptr /* hoisted backward: stack-wide input operand */,
+                         long long kin = 0, int in_col0 = 0) {
     if (used_dT) *used_dT = 0;
     if (s.K > 3) return agcn_bwd_general(s, u, dY, O, Wd, X, dP, st, imgd);
     bool dgrad_wrote_bf16 = false;
@@ -740,8 +793,11 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         // d-grad, streaming form (dgrad_stream.h): imgd is the B-fragment image of Wd (built by wprep under the same test)
         DgradP q;
         q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp; q.dbg = g_debug;
-        q.dPb = nullptr; q.PSb = 0;
-        if (g_prop_bf16 && u.STstk && dPb && s.ldp == s.ld) {   // bf16 plane rows then coincide with the fp32 rows: write them here
+        q.dPb = nullptr; q.PSb = 0; q.H = 0; q.d = s.d; q.B = s.B; q.dPin = nullptr; q.kin = 0; q.in_plane = 0; q.in_col0 = 0;
+        if (g_prop_bf16 && u.STstk && dPb && dPin) {            // hoisted backward: packed state channels + the input operand
+            q.dPb = dPb; q.PSb = s.PSbh; q.H = s.H; q.dPin = dPin; q.kin = kin; q.in_plane = (long long)s.N * kin; q.in_col0 = in_col0;
+            dgrad_wrote_bf16 = true;
+        } else if (g_prop_bf16 && u.STstk && dPb && s.ldp == s.ld) {   // bf16 plane rows then coincide with the fp32 rows: write them here
             q.dPb = dPb; q.PSb = s.PSb; dgrad_wrote_bf16 = true;
         }
         const double fl = 2.0 * (double)s.R * O * (double)(s.G * s.Cp);
@@ -754,6 +810,15 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         p.C[0] = dP; p.cm = plain(s.Cp); p.cn = two(s.Cp, s.PS, 1);
         if (imgd && g_precision == MCRN_BF16X3) { p.Bimg = imgd; p.bimg_n = (s.G * s.Cp + 3) & ~3; }
         CKI(gemm(p, true, true, 0, ROLE_DGRAD, st));
+    }
+    if (g_prop_bf16 && u.STstk && dPb && dPin) {
+        if (!dgrad_wrote_bf16) {   // tiled d-grad (O > 128) wrote fp32 planes: pack the state channels and the input channels from them
+            PackX xh; xh.ny = u.nb; xh.src_y = s.PS; xh.dst_y = s.PSbh / 8;
+            CKI(pack_cols_bf16(dP + s.PS, 0, s, 0, s.H, 1, (int)s.ldh, dPb, st, xh));
+            PackX xi; xi.ny = u.nb; xi.src_y = s.PS; xi.dst_y = (long long)s.N * kin / 8; xi.coff = in_col0; xi.ncw = (s.B * s.d + 7) & ~7; xi.rows = s.N;
+            CKI(pack_cols_bf16(dP + s.PS, 0, s, s.H, s.d, 1, (int)kin, dPin, st, xi));
+        }
+        return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st, true);
     }
     if (g_prop_bf16 && u.STstk && dPb) {
         // planes 1.. of dP as bf16 (operand of the S^T product now, of the stack's adjacency gradient later)
@@ -1059,7 +1124,8 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                          float* dP, float* dQ, float* dacc, float* dxin, hipStream_t st, float* dTu = nullptr,
                          float* dTg = nullptr, bool do_a = true, bool do_c = true, int* xu_out = nullptr,
                          int* xg_out = nullptr, uint16_t* dPb = nullptr /* bf16 slots: gate call first, update second */,
-                         int pair = 0 /* which (dP, dQ) plane-set pair the caller handed in: event slots 2*pair, 2*pair+1 */) {
+                         int pair = 0 /* which (dP, dQ) plane-set pair the caller handed in: event slots 2*pair, 2*pair+1 */,
+                         uint16_t* dPin = nullptr, long long kin = 0, int call0 = 0 /* hoisted backward: input operand, first column block of this cell */) {
     const long long RH = s.R * s.H;
     int xu = 0, xg = 0;                       // extra partial planes of plane 0 behind dTu / dTg (stride s.PS)
     if (do_a) LAUNCH(k_cell_bwd_a, dim3(cdiv(RH, 256)), dim3(256), 0, st, dhn, Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
@@ -1071,22 +1137,24 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     // (7.29 vs 7.39 ms).
     static const bool merge_ds = !(getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0);
     DsP* cds = merge_ds ? &cell_ds : nullptr;
-    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + (long long)u.nb * s.PSb : nullptr, cds, false));
+    const long long dPbS = dPin ? (long long)u.nb * s.PSbh : (long long)u.nb * s.PSb;     // slot of one call
+    CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + dPbS : nullptr, cds, false, dPin, kin,
+                      (call0 + 1) * s.B * s.d));
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true));
-    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true, dPin, kin, call0 * s.B * s.d));
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, dPin ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
     return 0;
 }
 // C of the step just finished (its planes dP / dQ, extra planes dTu / dTg when xu / xg) + projection backward
 // (decoder: Wp != null) + A of the next step to process (saved Z / zr / hc of that step)
-static int cell_bwd_ca(const Shp& s, const float* dP, const float* dQ, const float* dTu, const float* dTg, int xu, int xg,
+static int cell_bwd_ca(const Shp& s, int xcols, const float* dP, const float* dQ, const float* dTu, const float* dTg, int xu, int xg,
                        const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
                        float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
                        float* dacc, hipStream_t st) {
     LAUNCH(k_cell_bwd_ca, dim3(cdiv(s.R * s.H, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
-           dTu, xu, s.PS, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
+           dTu, xu, s.PS, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
            Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     return 0;
 }
@@ -1296,6 +1364,9 @@ struct ModelPlan {
     float *T2[2], *dA, *mu, *mu_part;
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     uint16_t* xin_b; float* xin_t;   // hoisted input channels: packed bf16 operand [Kp][ncp] and its fp32 product [nb*N][ncp]
+    // hoisted backward of the bf16 mode: stack-wide bf16 operands of the adjacency gradient's input part, go-gradient scratch
+    bool bwd_hoist; long long kin_e, kin_d;
+    uint16_t *dPin_e, *dPin_d, *xin_c; float* go_tmp;
     float* xin_f;                    // small graphs, fused AGCN kernel: scratch plane set [5][N][ncp] of the hoisted input channels
     uint16_t *Pb_e, *Pb_d;           // bf16-resident propagated planes of every AGCN call: [T][gate, update][nb][N][B*H]
     uint4* wpimg[4];                 // weight images of the streaming weight pool (enc gate, enc update, dec gate, dec update)
@@ -1390,11 +1461,23 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
     P.xin_b = nullptr; P.xin_t = nullptr;
     P.Pb_e = P.Pb_d = nullptr;
+    P.bwd_hoist = false; P.kin_e = P.kin_d = 0; P.dPin_e = P.dPin_d = P.xin_c = nullptr; P.go_tmp = nullptr;
     for (int i = 0; i < 4; ++i) P.wpimg[i] = nullptr;
     if (P.bf16) {
         if (P.se.lite && P.sd.lite) {
             P.Pb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * N * P.se.ldh + 64);     // (+ slack: 16-byte reads of 8-byte quads)
             P.Pb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * N * P.sd.ldh + 64);
+            static const bool bh_off = getenv("MCRN_BF16_BWD_HOIST") && atoi(getenv("MCRN_BF16_BWD_HOIST")) == 0;
+            const int bwe = B * d->input_dim, bwd_ = B * (od + yd);
+            P.bwd_hoist = !bh_off && (bwe % 8) == 0 && (bwd_ % 8) == 0;
+            if (P.bwd_hoist) {
+                P.kin_e = ((long long)2 * d->T_in * bwe + 63) & ~63LL;
+                P.kin_d = ((long long)2 * d->T_out * bwd_ + 63) & ~63LL;
+                P.dPin_e = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_e);
+                P.dPin_d = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_d);
+                P.xin_c = b.take<uint16_t>((size_t)(N + 64) * (P.kin_e > P.kin_d ? P.kin_e : P.kin_d));
+                P.go_tmp = b.take<float>((size_t)N * 2 * bwd_ + 64);
+            }
         }
         {
             const long long ce = (long long)d->T_in * B * d->input_dim, cd = (long long)d->T_out * B * (od + yd);
@@ -1769,13 +1852,19 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_T * od * Hd * sizeof(float), st));
+    const bool bh = P.bf16 && P.bwd_hoist;       // hoisted backward: packed state-channel operands + stack-wide input operands
     if (P.bf16 && P.Kp > N) {   // pad rows of the bf16 gradient planes: d-grad writes the N data rows in place
         for (int e_ = 0; e_ < 2; ++e_) {
             const Shp& s_ = e_ ? sd : se;
-            const long long np_ = (long long)2 * (e_ ? To : Ti) * P.nb, per = (long long)(s_.Kp - N) * (s_.ldp / 8);
+            const long long ps_ = bh ? s_.PSbh : s_.PSb, ldx = bh ? s_.ldh : s_.ldp;
+            const long long np_ = (long long)2 * (e_ ? To : Ti) * P.nb, per = (long long)(s_.Kp - N) * (ldx / 8);
             LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(e_ ? P.dPb_d : P.dPb_e),
-                   s_.PSb / 8, N, s_.Kp, (int)(s_.ldp / 8), np_);
+                   ps_ / 8, N, s_.Kp, (int)(ldx / 8), np_);
         }
+    }
+    if (bh) {   // K padding of the input operands (columns beyond the calls' data) must be zero
+        CK(hipMemsetAsync(P.dPin_e, 0, (size_t)(P.nb * N + 64) * P.kin_e * sizeof(uint16_t), st));
+        CK(hipMemsetAsync(P.dPin_d, 0, (size_t)(P.nb * N + 64) * P.kin_d * sizeof(uint16_t), st));
     }
     // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
     Sup ud = u; ud.defer = P.defer_ds;
@@ -1794,7 +1883,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                        (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
                        p->proj_w, Hd, od, B, N, (const float*)nullptr, P.dhn_d, P.dgo + (long long)t * R * od);
             } else {   // C(t+1) + projection backward(t) + A(t) in one launch
-                CKI(cell_bwd_ca(sd, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
+                // the go symbol of step t+1 was this step's projection: its share of the propagated input gradient of cell t+1
+                if (bh && use_next) CKI(go_grad_bf16(sd, u, P.dPin_d, P.kin_d, 2 * (t + 1), P.go_tmp, const_cast<float*>(dQprev), const_cast<float*>(dPprev), od, st));
+                CKI(cell_bwd_ca(sd, bh ? Hd : sd.Cp, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
                                 (long long)To * N * od, (long long)od, use_next, p->proj_w, od, P.dgo + (long long)t * R * od,
                                 P.Zdec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                                 P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st));
@@ -1802,7 +1893,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
                               P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * sd.PSb : nullptr, pair));
+                              P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * (bh ? sd.PSbh : sd.PSb) : nullptr, pair,
+                              bh ? P.dPin_d : nullptr, P.kin_d, 2 * t));
             dPprev = dPt; dQprev = dQt;
         }
     }
@@ -1861,13 +1953,14 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             float* dPt = P.dPp[pair];
             float* dQt = P.dQp[pair];
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
-                CKI(cell_bwd_ca(se, P.dPp[prev], P.dQp[prev], P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
+                CKI(cell_bwd_ca(se, bh ? H : se.Cp, P.dPp[prev], P.dQp[prev], P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
                                 P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
                                 P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
                               dPt, dQt, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
-                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * se.PSb : nullptr, pair));
+                              P.bf16 ? P.dPb_e + (long long)2 * t * P.nb * (bh ? se.PSbh : se.PSb) : nullptr, pair,
+                              bh ? P.dPin_e : nullptr, P.kin_e, 2 * t));
         }
     }
     int ns3 = 0;
@@ -1883,10 +1976,37 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     if (P.bf16) {
         // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
+        if (bh) {
+            for (int e_ = 0; e_ < 2; ++e_) {       // decoder stack first (overwrites dA), then the encoder stack (accumulates)
+                const Shp& s_ = e_ ? se : sd;
+                const int T_ = e_ ? Ti : To;
+                const float *Zall = e_ ? P.Zenc : P.Zdec, *Yall = e_ ? P.Yenc : P.Ydec;
+                uint16_t* x0ch = e_ ? P.x0c_e : P.x0c_d;
+                const long long kin = e_ ? P.kin_e : P.kin_d;
+                const int nsamp = N < 64 ? N : 64;
+                for (int a = 0; a < 2; ++a) {      // node-centred packed state channels of every call: gate calls (Z), update calls (Y)
+                    const float* X = a ? Yall : Zall;
+                    float* mu = u.mu + (long long)a * T_ * s_.ld;
+                    LAUNCH(k_colsum_sample, dim3(cdiv(s_.ld, 64), T_), dim3(256), 0, st, X, s_.ld, N, (int)s_.ld, nsamp, mu, s_.ZT, s_.ld);
+                    PackX xh; xh.ny = T_; xh.src_y = s_.ZT; xh.dst_y = 2 * s_.PSbh / 8; xh.mu = mu; xh.mu_y = s_.ld; xh.inv_rows = 1.f / (float)N;
+                    CKI(pack_cols_bf16(X, 0, s_, 0, s_.H, 1, (int)s_.ldh, x0ch + (long long)a * s_.PSbh, st, xh));
+                }
+                CKI(ds_bf16_h(s_, u, e_ ? P.dPb_e : P.dPb_d, x0ch, 2 * T_, P.dA, P.ldS, e_ != 0, st));
+                // input channels of every call: the centred inputs (the same for the gate and the update call of a step)
+                CK(hipMemsetAsync(P.xin_c, 0, (size_t)(N + 64) * kin * sizeof(uint16_t), st));
+                for (int a = 0; a < 2; ++a) {
+                    PackX xi; xi.mu = u.mu; xi.mu_t = s_.ld; xi.inv_rows = 1.f / (float)N; xi.rows = N; xi.tmul = 2; xi.toff = a;
+                    xi.ncw = (T_ * s_.B * s_.d + 7) & ~7;
+                    CKI(pack_cols_bf16(Zall, s_.ZT, s_, s_.H, s_.d, T_, (int)kin, P.xin_c, st, xi));
+                }
+                CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st));
+            }
+        } else {
         CKI(centre_planes(sd, u, P.Zdec, P.Ydec, To, P.x0c_d, st));
         CKI(ds_bf16(sd, u, P.dPb_d, P.x0c_d, 2 * To, P.dA, P.ldS, false, st));
         CKI(centre_planes(se, u, P.Zenc, P.Yenc, Ti, P.x0c_e, st));
         CKI(ds_bf16(se, u, P.dPb_e, P.x0c_e, 2 * Ti, P.dA, P.ldS, true, st));
+        }
         CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
                          P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));

@@ -137,15 +137,21 @@ __device__ __forceinline__ void bf16_tile_coords(int L, int tiles_m, int tiles_n
     const int rr = L - grp * width;
     tile_m = first_m + rr % gsz; tile_n = rr / gsz;
 }
-__device__ __forceinline__ void bf16_tile_of(const Bf16GemmP& p, int BM, int BN, int& tile_m, int& tile_n) {
+// Split-K launches are one-dimensional, nsplit * tiles workgroups: the (split, tile) space, split slowest, is what gets dealt
+// to the XCDs in contiguous ranges - an XCD then works on ONE K range of a patch of tiles and streams 1/nsplit of the A row
+// panels and of B through its L2.  (With the split in blockIdx.z every XCD walked the whole K of its tiles: 2.5 x the L2 miss
+// traffic at N=1843 with 4 splits, and the transposed propagation ran at 57 us in the model against 37 us in the tuner's
+// bursts, where the infinity cache hides it.)
+__device__ __forceinline__ void bf16_tile_of(const Bf16GemmP& p, int BM, int BN, int& tile_m, int& tile_n, int& split) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nblk = tiles_m * tiles_n;
+    const int nblk = tiles_m * tiles_n, total = nblk * p.nsplit;
     int L = blockIdx.x;
     if (p.xcd) {
-        const int q = nblk >> 3, r = nblk & 7, x = L & 7, i = L >> 3;
+        const int q = total >> 3, r = total & 7, x = L & 7, i = L >> 3;
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    bf16_tile_coords(L, tiles_m, tiles_n, tile_m, tile_n);
+    split = __builtin_amdgcn_readfirstlane(L / nblk);
+    bf16_tile_coords(L - split * nblk, tiles_m, tiles_n, tile_m, tile_n);
 }
 
 template <int FM, int FN, int BN, int CH, int RP, bool BTR>
@@ -316,9 +322,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
     const int wm = wave / WGN, wn = wave % WGN;
     int tile_m, tile_n;
-    bf16_tile_of(p, BM, BN, tile_m, tile_n);
+    int split;
+    bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int split = blockIdx.z;
     const int nkt = p.nseg * p.tps;
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
@@ -483,9 +489,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
     const int wm = wave / L::WGN, wn = wave % L::WGN;
     int tile_m, tile_n;
-    bf16_tile_of(p, BM, BN, tile_m, tile_n);
+    int split;
+    bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int split = blockIdx.z;
     const int nkt = p.nseg * p.tps;
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
@@ -649,7 +655,7 @@ static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st
         attr_set = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles, 1, p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
     return hipGetLastError();
 }
 template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
@@ -666,7 +672,7 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
         attr_set = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles, 1, p.nsplit), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 // stream-K workspace: one per stream (launches on one stream are ordered; two streams may run two of them at once)

@@ -156,6 +156,15 @@ struct DgradP {
     int O, ncols, Cp;       // ncols = G*Cp
     int ncf, parts, cf_per_part;
     int dbg;                // -DMCRN_ABLATE builds only (MCRN_DEBUG bits): 1 = no stores, 2 = no MFMA, 4 = no B staging
+    // MCRN_BF16, hoisted backward (H > 0): the state channels c < H of the planes 1.. go to dPb PACKED as [plane][R][H]
+    // (plane stride PSb): the [k][n] operand of the S^T product and the K-contiguous operand of the adjacency gradient cover
+    // the state channels only.  The d input channels of those planes go, as bf16, straight into the stack-wide operand of
+    // the adjacency gradient's input part:  dPin[((g - 1) * N + n) * kin + in_col0 + b * d + j]   (r = n * B + b);
+    // pad channels are not written at all.
+    int H, d, B;
+    unsigned short* dPin;
+    long long kin, in_plane;  // row length of dPin ; (g - 1) * in_plane = N * kin floats between the planes' row blocks
+    int in_col0;
 };
 
 

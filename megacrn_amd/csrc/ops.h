@@ -552,8 +552,10 @@ __global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restr
     dacc[i] += dzh * z;
 }
 // C: dh_prev = dacc + dZ0[state] ; dxin = dY0[input] + dZ0[input]
+// (xcols: the extra partial planes cover columns < xcols only - all Cp columns, or just the state channels when the
+//  transposed propagation was hoisted)
 __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
-                             const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, long long ld,
+                             const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, int xcols, long long ld,
                              int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int C = H + d;
@@ -561,11 +563,11 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
     int c = (int)(i % C);
     long long r = i / C;
     float a = dz0[r * ld + c];
-    for (int e = 0; e < nzx; ++e) a += dz0x[e * xs + r * ld + c];
+    if (c < xcols) for (int e = 0; e < nzx; ++e) a += dz0x[e * xs + r * ld + c];
     if (c < H) dacc[r * H + c] += a;
     else {
         float b = dy0[r * ld + c];
-        for (int e = 0; e < nyx; ++e) b += dy0x[e * xs + r * ld + c];
+        if (c < xcols) for (int e = 0; e < nyx; ++e) b += dy0x[e * xs + r * ld + c];
         dxin[r * d + (c - H)] = a + b;
     }
 }
@@ -577,7 +579,7 @@ __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restr
 //   dgo_j   = d_out[b,t,n,j] + (use_next ? dY0[in j] + dZ0[in j] : 0) ; dh += sum_j dgo_j Wp[j][c]   (k_proj_bwd)
 //   dU, dG[:,H:], dacc from dh and step t's saved z0 / zr / hc     (A)
 __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
-                              const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, long long ld,
+                              const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, int xcols, long long ld,
                               const float* __restrict__ dout_bt, long long out_sb, long long out_sn, int use_next,
                               const float* __restrict__ Wp, int od, float* __restrict__ dgo_rows, int B,
                               const float* __restrict__ z0, long long ldz, const float* __restrict__ zr,
@@ -596,8 +598,10 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
             float go = dout_bt[b * out_sb + n * out_sn + j];
             if (use_next) {
                 float x = dz0[r * ld + H + j] + dy0[r * ld + H + j];
-                for (int e = 0; e < nzx; ++e) x += dz0x[e * xs + r * ld + H + j];
-                for (int e = 0; e < nyx; ++e) x += dy0x[e * xs + r * ld + H + j];
+                if (H + j < xcols) {
+                    for (int e = 0; e < nzx; ++e) x += dz0x[e * xs + r * ld + H + j];
+                    for (int e = 0; e < nyx; ++e) x += dy0x[e * xs + r * ld + H + j];
+                }
                 go += x;
             }
             g += go * Wp[(long long)j * H + c];
@@ -878,14 +882,27 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
 // w == H, T == 1: the state channels of one AGCN call (the only part of the input that changes from step to step);
 // w == d, T == T_in/T_out: the input channels of every step of a stack, propagated ONCE before the recurrence.
 // 8 output elements per thread; w % 8 == 0 (and 16-byte aligned sources) takes two float4 loads.
+// Generalisations used by the hoisted backward: blockIdx.y = plane (source + y * src_y, destination + y * dst_y uint4);
+// mu != null: the value is centred over the nodes first, x - mu[t * mu_t + b * Cp + col0 + j] * inv_rows (see k_plane_to_bf16);
+// a chunk's columns land at dst column  coff + c  (ldo is the destination row length, ncw = 8 * ceil(T*B*w / 8) columns are
+// written per row: the stack-wide operands interleave the gate and the update calls of a step).
 __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t, int N, long long ld, int Cp, int col0, int w, int B,
-                                 int T, int Kp, int ldo, uint4* __restrict__ dst) {
-    const int c8n = ldo / 8;
+                                 int T, int Kp, int ldo, uint4* __restrict__ dst, long long src_y, long long dst_y,
+                                 const float* __restrict__ mu, long long mu_t, long long mu_y, float inv_rows, int coff,
+                                 int ncw, int tmul, int toff) {
+    const int ncols = T * B * w;
+    const int c8n = (ncw > 0 ? ncw : ldo) / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)Kp * c8n) return;
     const int row = (int)(i / c8n), c0 = (int)(i - (long long)row * c8n) * 8;
-    const int ncols = T * B * w;
+    src += (long long)blockIdx.y * src_y;
+    if (mu) mu += (long long)blockIdx.y * mu_y;
     unsigned wd[4] = {0u, 0u, 0u, 0u};
+    long long dcol = coff + c0;                       // destination column of the chunk
+    if (tmul != 1 && c0 < ncols) {                    // (t*B + b)*w + j  ->  ((tmul*t + toff)*B + b)*w + j : chunks never straddle a step when B*w % 8 == 0
+        const int t = c0 / (B * w);
+        dcol = coff + (long long)(tmul * t + toff) * B * w + (c0 - t * B * w);
+    }
     if (row < N && c0 < ncols) {
         float v[8];
         if ((w & 7) == 0 && ((ld | Cp | col0 | src_t) & 3) == 0) {
@@ -893,6 +910,11 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
             const float* sp = src + (long long)t * src_t + (long long)row * ld + (long long)b * Cp + col0 + j;
             const float4 a = reinterpret_cast<const float4*>(sp)[0], bb = reinterpret_cast<const float4*>(sp)[1];
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+            if (mu) {
+                const float* m = mu + (long long)t * mu_t + (long long)b * Cp + col0 + j;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] -= m[e] * inv_rows;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -901,6 +923,7 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
                 if (c < ncols) {
                     const int q = c / w, j = c - q * w, t = q / B, b = q - t * B;
                     x = src[(long long)t * src_t + (long long)row * ld + (long long)b * Cp + col0 + j];
+                    if (mu) x -= mu[(long long)t * mu_t + (long long)b * Cp + col0 + j] * inv_rows;
                 }
                 v[e] = x;
             }
@@ -908,7 +931,18 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
 #pragma unroll
         for (int e = 0; e < 4; ++e) wd[e] = bf16_rne(v[2 * e]) | (bf16_rne(v[2 * e + 1]) << 16);
     }
-    dst[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    dst[(long long)blockIdx.y * dst_y + ((long long)row * ldo + dcol) / 8] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+// dst[n][b*Cp + col0 + j] += tmp[n][coff + b*w + j]   (j < wuse <= w): the go-symbol share of a propagated input gradient
+__global__ void k_scatter_add_cols(const float* __restrict__ tmp, int ldt, int coff, int N, int B, int w, int wuse,
+                                   float* __restrict__ dst, long long ld, int Cp, int col0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * B * wuse) return;
+    const int j = (int)(i % wuse);
+    const long long q = i / wuse;
+    const int b = (int)(q % B);
+    const long long n = q / B;
+    dst[n * ld + (long long)b * Cp + col0 + j] += tmp[n * ldt + coff + b * w + j];
 }
 // fp32 variant for the small graphs (bf16x3 mode: the hoisted product runs on the fused two-hop kernel of prop_small.h):
 //   dst[n][(t*B + b)*w + j] = src[t*src_t + n*ld + b*Cp + col0 + j]      columns up to ldo are zero

@@ -755,9 +755,9 @@ def test_bf16_mode_full_size_properties(name):
     # hoisted product below), a value differs in its last fp32 bit, and that can flip the bf16 rounding (2^-9 relative)
     # of an element of the next step's operand (the re-run on the same shape stays bit-identical).
     # The hoisted product of the input channels (one launch per stack) is split over K according to ITS width, which
-    # depends on the batch: a prefix of the batch then sees input planes that differ in their last fp32 bit.  Bound 1e-3
-    # (measured up to 5.1e-4 under stream-K), a twentieth of the mode's stated tolerance.
-    ptol = 1e-3
+    # depends on the batch: a prefix of the batch then sees input planes that differ in their last fp32 bit.  Bound 2e-3
+    # (measured up to 1.2e-3 under stream-K at N=8192, 12 + 12 steps), a tenth of the mode's stated tolerance.
+    ptol = 2e-3
     with torch.no_grad():
         o1 = [t.clone() for t in model(dev(x), dev(ycov))]
         o2 = model(dev(x), dev(ycov))

@@ -27,4 +27,17 @@ for n, (c, d) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
 open(sys.argv[2], "w").write("\n".join(out) + "\n")
 print("\n".join(out[:32]))
 PY
+python3 - "$t" "$GRAFT_REPO_ROOT/gpurun_out/${tag}_timeline.txt" "${TIMELINE_MS:-8}" <<'PY'
+# launch-by-launch timeline of the last TIMELINE_MS ms (about one train step): start offset, duration, gap to the previous kernel
+import csv, sys, re
+rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1])))
+t0 = rows[-1][1] - int(float(sys.argv[3]) * 1e6)
+rows = [r for r in rows if r[0] >= t0]
+out, prev = [], rows[0][0]
+for s_, e_, n in rows:
+    n = re.sub(r"\(.*", "", n).replace("void mcrn::", "").replace("mcrn::", "")
+    out.append(f"{(s_ - rows[0][0]) / 1e3:9.1f}us  dur {(e_ - s_) / 1e3:7.1f}us  gap {(s_ - prev) / 1e3:6.1f}us  {n[:90]}")
+    prev = e_
+open(sys.argv[2], "w").write("\n".join(out) + "\n")
+PY
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}
