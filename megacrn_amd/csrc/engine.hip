@@ -892,6 +892,8 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             }
             {
                 hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
+                static const bool dbg_skip = getenv("MCRN_DBG_SKIP_DS") != nullptr;   // timing experiments only (wrong gradients)
+                if (!dbg_skip)
                 MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st), ex, 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
             }
             if (side) {

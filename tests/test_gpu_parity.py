@@ -695,6 +695,8 @@ BF16_TOL = 2e-2        # stated tolerance of the mode (max-norm relative, like T
     (300, 3, 3, 12, 6, 8, 3),        # odd batch: plane rows padded to 8 channels; K tail of 300 = 4 x 64 + 44
     (261, 4, 2, 12, 6, 8, 2),        # cheb_k = 2: two stacked blocks, no T2
     (1843, 4, 6, 32, 10, 32, 3),     # EXPY-TKY geometry at a reduced batch
+    (1843, 8, 3, 32, 10, 32, 3),     # ... at a batch the hoisted backward takes (B * input channels % 8 == 0): packed state-channel
+                                     #     planes, stack-wide input operands, the go-symbol product of the non-teacher steps
     (8192, 2, 2, 64, 20, 64, 3),     # SYN-8192 geometry (the mode bench.py runs it in) at a reduced batch / sequence
 ])
 def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
@@ -865,6 +867,7 @@ def test_packed_fp32_erratum_reproducer_and_guard():
     ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 1843)"),   # tiled weight pool
     ({"MCRN_HOIST": "0"}, "bf16_mode_train and 1843"),               # bf16 mode without hoisting (all B*Cp columns per step)
     ({"MCRN_BF16_PLANES": "0"}, "bf16_mode_train and 1843"),         # hoisted propagation into fp32 planes (no bf16-resident planes)
+    ({"MCRN_BF16_BWD_HOIST": "0"}, "bf16_mode_train and 1843"),      # hoisted forward, full-width backward
 ])
 def test_alternative_paths_keep_parity(env, select):
     import subprocess
