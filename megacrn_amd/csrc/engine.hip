@@ -1934,6 +1934,39 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
     int ns2 = 0;
     CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
+    // hoisted backward, adjacency gradient of one cell stack (K-concatenated over every AGCN call); with MCRN_BF16_DS_SIDE=1 the
+    // decoder's runs on the helper stream behind its weight gradients and overlaps the encoder BPTT; the encoder's accumulates
+    // into the same dA after the join
+    auto stack_ds = [&](int e_, hipStream_t st) -> int {
+        const Shp& s_ = e_ ? se : sd;
+        const int T_ = e_ ? Ti : To;
+        const float *Zall = e_ ? P.Zenc : P.Zdec, *Yall = e_ ? P.Yenc : P.Ydec;
+        uint16_t* x0ch = e_ ? P.x0c_e : P.x0c_d;
+        const long long kin = e_ ? P.kin_e : P.kin_d;
+        const int nsamp = N < 64 ? N : 64;
+        for (int a = 0; a < 2; ++a) {      // node-centred packed state channels of every call: gate calls (Z), update calls (Y)
+            const float* X = a ? Yall : Zall;
+            float* mu = u.mu + (long long)a * T_ * s_.ld;
+            LAUNCH(k_colsum_sample, dim3(cdiv(s_.ld, 64), T_), dim3(256), 0, st, X, s_.ld, N, (int)s_.ld, nsamp, mu, s_.ZT, s_.ld);
+            PackX xh; xh.ny = T_; xh.src_y = s_.ZT; xh.dst_y = 2 * s_.PSbh / 8; xh.mu = mu; xh.mu_y = s_.ld; xh.inv_rows = 1.f / (float)N;
+            CKI(pack_cols_bf16(X, 0, s_, 0, s_.H, 1, (int)s_.ldh, x0ch + (long long)a * s_.PSbh, st, xh));
+        }
+        CKI(ds_bf16_h(s_, u, e_ ? P.dPb_e : P.dPb_d, x0ch, 2 * T_, P.dA, P.ldS, e_ != 0, st));
+        // input channels of every call: the centred inputs (the same for the gate and the update call of a step)
+        CK(hipMemsetAsync(P.xin_c, 0, (size_t)(N + 64) * kin * sizeof(uint16_t), st));
+        for (int a = 0; a < 2; ++a) {
+            PackX xi; xi.mu = u.mu; xi.mu_t = s_.ld; xi.inv_rows = 1.f / (float)N; xi.rows = N; xi.tmul = 2; xi.toff = a;
+            xi.ncw = (T_ * s_.B * s_.d + 7) & ~7;
+            CKI(pack_cols_bf16(Zall, s_.ZT, s_, s_.H, s_.d, T_, (int)kin, P.xin_c, st, xi));
+        }
+        CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st));
+        return 0;
+    };
+    bool ds_dec_done = false;
+    // (opt-in: measured neutral at N = 1843 and N = 8192 - 4273 vs 4261 and 120.5 vs 123.4 samples/s - the product is
+    //  MFMA-bound and full-chip, so it only trades places with the BPTT kernels it overlaps)
+    static const bool ds_side_on = getenv("MCRN_BF16_DS_SIDE") && atoi(getenv("MCRN_BF16_DS_SIDE")) == 1;
+    if (bh && ws_ != st && ds_side_on) { CKI(stack_ds(0, ws_)); ds_dec_done = true; }
     CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1, on1 ? g->dec_gate_b : nullptr));
     CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2, on2 ? g->dec_update_b : nullptr));
     if (!on1) CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
@@ -1979,30 +2012,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
         if (bh) {
-            for (int e_ = 0; e_ < 2; ++e_) {       // decoder stack first (overwrites dA), then the encoder stack (accumulates)
-                const Shp& s_ = e_ ? se : sd;
-                const int T_ = e_ ? Ti : To;
-                const float *Zall = e_ ? P.Zenc : P.Zdec, *Yall = e_ ? P.Yenc : P.Ydec;
-                uint16_t* x0ch = e_ ? P.x0c_e : P.x0c_d;
-                const long long kin = e_ ? P.kin_e : P.kin_d;
-                const int nsamp = N < 64 ? N : 64;
-                for (int a = 0; a < 2; ++a) {      // node-centred packed state channels of every call: gate calls (Z), update calls (Y)
-                    const float* X = a ? Yall : Zall;
-                    float* mu = u.mu + (long long)a * T_ * s_.ld;
-                    LAUNCH(k_colsum_sample, dim3(cdiv(s_.ld, 64), T_), dim3(256), 0, st, X, s_.ld, N, (int)s_.ld, nsamp, mu, s_.ZT, s_.ld);
-                    PackX xh; xh.ny = T_; xh.src_y = s_.ZT; xh.dst_y = 2 * s_.PSbh / 8; xh.mu = mu; xh.mu_y = s_.ld; xh.inv_rows = 1.f / (float)N;
-                    CKI(pack_cols_bf16(X, 0, s_, 0, s_.H, 1, (int)s_.ldh, x0ch + (long long)a * s_.PSbh, st, xh));
-                }
-                CKI(ds_bf16_h(s_, u, e_ ? P.dPb_e : P.dPb_d, x0ch, 2 * T_, P.dA, P.ldS, e_ != 0, st));
-                // input channels of every call: the centred inputs (the same for the gate and the update call of a step)
-                CK(hipMemsetAsync(P.xin_c, 0, (size_t)(N + 64) * kin * sizeof(uint16_t), st));
-                for (int a = 0; a < 2; ++a) {
-                    PackX xi; xi.mu = u.mu; xi.mu_t = s_.ld; xi.inv_rows = 1.f / (float)N; xi.rows = N; xi.tmul = 2; xi.toff = a;
-                    xi.ncw = (T_ * s_.B * s_.d + 7) & ~7;
-                    CKI(pack_cols_bf16(Zall, s_.ZT, s_, s_.H, s_.d, T_, (int)kin, P.xin_c, st, xi));
-                }
-                CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st));
-            }
+            if (!ds_dec_done) CKI(stack_ds(0, st));
+            CKI(stack_ds(1, st));
         } else {
         CKI(centre_planes(sd, u, P.Zdec, P.Ydec, To, P.x0c_d, st));
         CKI(ds_bf16(sd, u, P.dPb_d, P.x0c_d, 2 * To, P.dA, P.ldS, false, st));
