@@ -1,6 +1,6 @@
 // dgrad_stream.h - plane-gradient GEMM of the AGCN backward, gfx950, bf16x3 arithmetic.
 //
-//   dP[g][r][c'] = sum_o dY[r][o] * Wd[(g, c')][o]          r < R = N*B rows, (g, c') < G*Cp columns, o < O <= 128
+//   dP[g][r][c'] = sum_o dY[r][o] * Wd[(g, c')][o]          r < R = N*B rows, (g, c') < G*Cp columns, o < O <= 256
 //
 // Small K (O = 2H or H), wide N (G*Cp = 340 / 680 at METR-LA), huge M: the product is bound by its 18 / 36 MB of
 // output.  In the tiled GEMM a 128x128 workgroup spent 3.1 us in its prologue and 4.4 us in its store epilogue around
@@ -40,12 +40,15 @@ static __global__ void k_wfrag_build(const float* __restrict__ W, long long ld, 
     out[((long long)(j * KS + ks) * 2 + 0) * 64 + lane] = h;
     out[((long long)(j * KS + ks) * 2 + 1) * 64 + lane] = l;
 }
-template <int KS>
+// KH = 2 (128 < O <= 256, the decoder gate of the H = 64 configurations): the K extent is walked in two halves of KS
+// k-steps; the wave keeps BOTH halves of its dY rows resident (16 KS VGPRs), a column fragment is staged and multiplied
+// half by half into the same accumulators and stored after the second.
+template <int KS, int KH = 1>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) void dgrad_stream_kernel(const DgradP p) {   // <= 3 waves per SIMD: keeps the compiler from spilling the staging registers to reach a higher occupancy
-    constexpr int FRAG = KS * 2 * 64;                                 // uint4 per column fragment (hi and lo, all k-steps)
-    constexpr int NLD = (FRAG + 255) / 256;                           // uint4 per thread to stage one fragment
-    constexpr int O = 16 * KS;
-    constexpr int AROW = O + 4;                                       // padded row (floats) of the A bounce buffer
+    constexpr int FRAG = KS * 2 * 64;                                 // uint4 per staged piece: one column fragment, one K half (hi and lo)
+    constexpr int NLD = (FRAG + 255) / 256;                           // uint4 per thread to stage one piece
+    constexpr int OH = 16 * KS, O = OH * KH;                          // columns of dY per half / in all
+    constexpr int AROW = OH + 4;                                      // padded row (floats) of the A bounce buffer
     constexpr int ABYTES = 4 * 32 * AROW * 4, BBYTES = 2 * FRAG * 16;
     // one LDS region: first the four waves' A bounce buffers, then (after a barrier) the two B stages
     __shared__ __attribute__((aligned(16))) unsigned char smem_[ABYTES > BBYTES ? ABYTES : BBYTES];
@@ -68,28 +71,30 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
     // 128*O-byte block of dY: it is read with fully coalesced 16-byte loads and bounced through LDS into fragment
     // order.  (Reading it directly in fragment order - 32 bytes per lane from 32 different rows - used a quarter of
     // every 128-byte line it touched and alone cost 20 of the kernel's 25 us.)
-    uint4 ah[KS], al[KS];
+    uint4 ah[KH * KS], al[KH * KS];
     {
         float* __restrict__ sa = reinterpret_cast<float*>(smem_) + wave * 32 * AROW;
-        const long long base = rf * 32 * O;                           // first float of the block
         const long long lim = p.R * O;                                // floats in dY
 #pragma unroll
-        for (int i = 0; i < O / 8; ++i) {                             // 32*O/4 float4 over 64 lanes
-            const int e = lane + 64 * i;                              // float4 index inside the block
-            long long src = base + 4LL * e;
-            if (src + 4 > lim) src = lim - 4;                         // rows beyond R: any valid address, never stored
-            if (src < 0) src = 0;
-            const float4 x = *reinterpret_cast<const float4*>(p.dY + src);
-            const int row = (4 * e) / O, k = (4 * e) % O;
-            *reinterpret_cast<float4*>(sa + row * AROW + k) = x;
-        }
-        // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+        for (int h = 0; h < KH; ++h) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float4 x = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq);
-            const float4 y = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq + 4);
-            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-            split8(v, ah[ks], al[ks]);
+            for (int i = 0; i < OH / 8; ++i) {                        // 32*OH/4 float4 over 64 lanes
+                const int e = lane + 64 * i;                          // float4 index inside the (32 x OH) block
+                const int row = (4 * e) / OH, k = (4 * e) % OH;
+                long long src = (rf * 32 + row) * O + h * OH + k;     // (KH == 1: the 32 rows are one contiguous block)
+                if (src + 4 > lim) src = lim - 4;                     // rows beyond R: any valid address, never stored
+                if (src < 0) src = 0;
+                const float4 x = *reinterpret_cast<const float4*>(p.dY + src);
+                *reinterpret_cast<float4*>(sa + row * AROW + k) = x;
+            }
+            // same wave wrote and reads (and overwrites for the next half): LDS operations of a wave complete in order
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 x = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq);
+                const float4 y = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq + 4);
+                const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+                split8(v, ah[h * KS + ks], al[h * KS + ks]);
+            }
         }
     }
     __syncthreads();                                                  // the B stages reuse the bounce buffers
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
 
     // staging registers as four scalars (NLD <= 4): as an array - lambda-captured or not - they were kept in scratch
     uint4 s0 = make_uint4(0u, 0u, 0u, 0u), s1 = s0, s2 = s0, s3 = s0;
-    static_assert(NLD <= 4, "O <= 128");
+    static_assert(NLD <= 4, "O <= 128 per half");
 #define MCRN_DG_E(i) ((FRAG % 256 == 0 || tid + 256 * (i) < FRAG) ? tid + 256 * (i) : FRAG - 1)
 #define MCRN_DG_FETCH(J)                                                                       \
     do {                                                                                       \
@@ -119,19 +124,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         if constexpr (NLD > 2) { if (MCRN_DG_OK(2)) sB[S][tid + 512] = s2; }                   \
         if constexpr (NLD > 3) { if (MCRN_DG_OK(3)) sB[S][tid + 768] = s3; }                   \
     } while (0)
-    MCRN_DG_FETCH(j0);
+    MCRN_DG_FETCH(j0 * KH);                                           // (pieces are numbered j * KH + half, contiguous in Wfrag)
     MCRN_DG_PUBLISH(0);
     __syncthreads();
     for (int j = j0; j < j1; ++j) {
-        const int s = (j - j0) & 1;
-        if (j + 1 < j1 && !(dbg & 4)) MCRN_DG_FETCH(j + 1);          // in flight during the MFMA chain and the stores
         f32x16 acc, acx;                                               // main product / the two cross products
 #pragma unroll
         for (int v = 0; v < 16; ++v) { acc[v] = 0.f; acx[v] = 0.f; }
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+        const int s = KH == 1 ? ((j - j0) & 1) : h;                    // (an even number of pieces per fragment: the parity is the half)
+        const bool more = h + 1 < KH || j + 1 < j1;
+        if (more && !(dbg & 4)) MCRN_DG_FETCH(j * KH + h + 1);       // in flight during the MFMA chain and the stores
         if (!(dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]), xl = __builtin_bit_cast(bf16x8, al[ks]);
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[h * KS + ks]), xl = __builtin_bit_cast(bf16x8, al[h * KS + ks]);
             const bf16x8 yh = __builtin_bit_cast(bf16x8, sB[s][(ks * 2 + 0) * 64 + lane]);
             const bf16x8 yl = __builtin_bit_cast(bf16x8, sB[s][(ks * 2 + 1) * 64 + lane]);
             acx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acx, 0, 0, 0);
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
             acx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acx, 0, 0, 0);
         }
         const int n = 32 * j + l31;                                    // C/D layout: column = lane & 31
-        if (live && n < p.ncols && !(dbg & 1)) {
+        if (h == KH - 1 && live && n < p.ncols && !(dbg & 1)) {
             const int g = n / p.Cp;
             int cp = p.Cp;
             asm volatile("" : "+s"(cp));                               // row offsets stay scalar multiples, not 16 live VGPR pairs
@@ -191,8 +199,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
                 }
             }
         }
-        if (j + 1 < j1) MCRN_DG_PUBLISH(s ^ 1);                        // every wave left stage s^1 before the previous barrier
+        if (more) MCRN_DG_PUBLISH(s ^ 1);                              // every wave left stage s^1 before the previous barrier
         __syncthreads();
+        }   // halves
     }
 #undef MCRN_DG_FETCH
 #undef MCRN_DG_PUBLISH
@@ -220,6 +229,10 @@ static inline hipError_t launch_dgrad_stream(DgradP p, hipStream_t st) {
         case 6: hipLaunchKernelGGL(dgrad_stream_kernel<6>, grid, dim3(256), 0, st, p); break;
         case 7: hipLaunchKernelGGL(dgrad_stream_kernel<7>, grid, dim3(256), 0, st, p); break;
         case 8: hipLaunchKernelGGL(dgrad_stream_kernel<8>, grid, dim3(256), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((dgrad_stream_kernel<5, 2>), grid, dim3(256), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((dgrad_stream_kernel<6, 2>), grid, dim3(256), 0, st, p); break;
+        case 14: hipLaunchKernelGGL((dgrad_stream_kernel<7, 2>), grid, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL((dgrad_stream_kernel<8, 2>), grid, dim3(256), 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

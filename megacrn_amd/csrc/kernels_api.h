@@ -144,7 +144,7 @@ struct AgcnFP {
 
 // ---- streaming d-grad (dgrad_stream.h) -----------------------------------------------------------------------
 static inline size_t wfrag_uint4(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * 64; }
-static inline bool dgrad_stream_ok(int O) { return O % 16 == 0 && O >= 16 && O <= 128; }
+static inline bool dgrad_stream_ok(int O) { return O >= 16 && ((O % 16 == 0 && O <= 128) || (O % 32 == 0 && O <= 256)); }
 
 struct DgradP {
     const float* dY;        // [R][O]
