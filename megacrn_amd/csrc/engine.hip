@@ -1161,6 +1161,18 @@ static int cell_bwd_ca(const Shp& s, int xcols, const float* dP, const float* dQ
     return 0;
 }
 
+// row softmax of the adaptive adjacency and its backward: one wave per row on small graphs, one workgroup per row from N = 512
+static int relu_softmax_rows(const float* L, long long ldl, float* G, long long ldg, int N, hipStream_t st) {
+    if (N >= 512) LAUNCH(k_relu_softmax_rows<4>, dim3(N), dim3(256), 0, st, L, ldl, G, ldg, N);
+    else LAUNCH(k_relu_softmax_rows<1>, dim3(cdiv(N, 4)), dim3(256), 0, st, L, ldl, G, ldg, N);
+    return 0;
+}
+static int relu_softmax_rows_bwd(const float* L, long long ldl, const float* G, long long ldg, const float* dS, long long ldd,
+                                 int nslab, long long slab, float* dL, long long ldo, int N, hipStream_t st) {
+    if (N >= 512) LAUNCH(k_relu_softmax_rows_bwd<4>, dim3(N), dim3(256), 0, st, L, ldl, G, ldg, dS, ldd, nslab, slab, dL, ldo, N);
+    else LAUNCH(k_relu_softmax_rows_bwd<1>, dim3(cdiv(N, 4)), dim3(256), 0, st, L, ldl, G, ldg, dS, ldd, nslab, slab, dL, ldo, N);
+    return 0;
+}
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
 struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
 static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
@@ -1224,8 +1236,8 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
     }
     }   // exact_logits
     CKI(transpose(o.L2, o.ldS, o.L1, o.ldS, nullptr, 0, N, st));
-    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, N);
-    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, N);
+    CKI(relu_softmax_rows(o.L1, o.ldS, g1, ldg, N, st));
+    CKI(relu_softmax_rows(o.L2, o.ldS, g2, ldg, N, st));
     if (want_T) {
         CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
         CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
@@ -1250,8 +1262,8 @@ static int sup_bwd_core(int N, int M, int D, const float* We1, const float* We2,
         LAUNCH(k_reduce_slabs_groups, dim3(cdiv(n, 256), groups), dim3(256), 0, st, const_cast<float*>(dS2), nslab, slab, n, groups);
         nslab = groups;
     }
-    LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, g1, ldg, dS1, ldd, nslab, slab, o.dLa, o.ldS, N);
-    LAUNCH(k_relu_softmax_rows_bwd, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, g2, ldg, dS2, ldd, nslab, slab, o.dLb, o.ldS, N);
+    CKI(relu_softmax_rows_bwd(o.L1, o.ldS, g1, ldg, dS1, ldd, nslab, slab, o.dLa, o.ldS, N, st));
+    CKI(relu_softmax_rows_bwd(o.L2, o.ldS, g2, ldg, dS2, ldd, nslab, slab, o.dLb, o.ldS, N, st));
     CKI(transpose(o.dLs, o.ldS, o.dLb, o.ldS, o.dLa, o.ldS, N, st));   // dLs = dL1 + dL2^T
     // dE1 = dLs E2 and dE2 = dLs^T E1: N x D outputs (a few dozen tiles) over K = N: split K into NSLAB_E slabs so that the
     // launch fills the chip (at N = 1843 a single pass over K took ~80 us per product on 29 workgroups)
@@ -2356,8 +2368,8 @@ int mcrn_supports_backward(int N, int M, int D, const float* We1, const float* W
     SupBufs o;
     plan_sup(b, N, M, D, N, o);
     // recompute g1,g2 (forward left E1,E2,L1,L2 in ws; g were caller outputs) into St1/St2 scratch
-    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L1, o.ldS, o.St1, (long long)N, N);
-    LAUNCH(k_relu_softmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o.L2, o.ldS, o.St2, (long long)N, N);
+    CKI(relu_softmax_rows(o.L1, o.ldS, o.St1, (long long)N, N, st));
+    CKI(relu_softmax_rows(o.L2, o.ldS, o.St2, (long long)N, N, st));
     CK(hipMemsetAsync(dMem, 0, (size_t)M * D * sizeof(float), st));
     return sup_bwd_core(N, M, D, We1, We2, Mem, o, o.St1, o.St2, N, dg1, dg2, N, 1, 0, dWe1, dWe2, dMem, st);
 }

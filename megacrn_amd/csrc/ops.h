@@ -160,43 +160,66 @@ __global__ __launch_bounds__(1024) void k_wunprep(float* __restrict__ dW, const 
 // ---------------------------------------------------------------------------------------------
 // adjacency: g = rowsoftmax(relu(L))  (model/MegaCRN.py:171-172), one wave per row
 // ---------------------------------------------------------------------------------------------
+// WPR waves per row (a 256-thread workgroup holds 4 / WPR rows): one wave per row leaves a large graph's launch at ~2
+// waves per SIMD, each walking 29+ elements per lane through three dependent passes (N = 1843: 25 us forward, 63 us
+// backward); with the whole workgroup on one row the same passes are 4x shorter and 4x as many waves hide the latency.
+template <int WPR>
+__device__ __forceinline__ float rows_reduce(float v, bool is_max, float* red, int wave) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    if (WPR == 1) return v;
+    __syncthreads();                       // (the previous reduction's readers are done with `red`)
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < WPR; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+template <int WPR>
 __global__ void k_relu_softmax_rows(const float* __restrict__ L, long long ldl, float* __restrict__ G,
                                     long long ldg, int N) {
-    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (row >= N) return;
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * (4 / WPR) + wave / WPR;
+    const int lane = (wave % WPR) * 64 + (threadIdx.x & 63);
+    constexpr int STEP = 64 * WPR;
+    if (WPR == 1 && row >= N) return;      // (WPR == 4: one row per workgroup, the grid is exactly N)
     const float* l = L + (long long)row * ldl;
     float mx = 0.f;  // relu output is >= 0
-    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, l[c]);
-    mx = wave_max(mx);
+    for (int c = lane; c < N; c += STEP) mx = fmaxf(mx, l[c]);
+    mx = rows_reduce<WPR>(mx, true, red, wave);
     float s = 0.f;
-    for (int c = lane; c < N; c += 64) s += expf(fmaxf(l[c], 0.f) - mx);
-    s = wave_sum(s);
+    for (int c = lane; c < N; c += STEP) s += expf(fmaxf(l[c], 0.f) - mx);
+    s = rows_reduce<WPR>(s, false, red, wave);
     float inv = 1.f / s;
     float* g = G + (long long)row * ldg;
-    for (int c = lane; c < N; c += 64) g[c] = expf(fmaxf(l[c], 0.f) - mx) * inv;
+    for (int c = lane; c < N; c += STEP) g[c] = expf(fmaxf(l[c], 0.f) - mx) * inv;
 }
 
 // dL = g * (dS - sum(dS*g)) * [L > 0], dS = sum over slabs
+template <int WPR>
 __global__ void k_relu_softmax_rows_bwd(const float* __restrict__ L, long long ldl,
                                         const float* __restrict__ G, long long ldg,
                                         const float* __restrict__ dS, long long ldd, int nslab,
                                         long long slab, float* __restrict__ dL, long long ldo, int N) {
-    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (row >= N) return;
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * (4 / WPR) + wave / WPR;
+    const int lane = (wave % WPR) * 64 + (threadIdx.x & 63);
+    constexpr int STEP = 64 * WPR;
+    if (WPR == 1 && row >= N) return;
     const float* g = G + (long long)row * ldg;
     const float* l = L + (long long)row * ldl;
     const float* d = dS + (long long)row * ldd;
     float dot = 0.f;
-    for (int c = lane; c < N; c += 64) {
+    for (int c = lane; c < N; c += STEP) {
         float v = 0.f;
         for (int z = 0; z < nslab; ++z) v += d[z * slab + c];
         dot += v * g[c];
     }
-    dot = wave_sum(dot);
+    dot = rows_reduce<WPR>(dot, false, red, wave);
     float* o = dL + (long long)row * ldo;
-    for (int c = lane; c < N; c += 64) {
+    for (int c = lane; c < N; c += STEP) {
         float v = 0.f;
         for (int z = 0; z < nslab; ++z) v += d[z * slab + c];
         o[c] = l[c] > 0.f ? g[c] * (v - dot) : 0.f;

@@ -1,62 +1,96 @@
 #!/usr/bin/env python3
-"""Refresh the measured numbers quoted in README.md, DESIGN.md section 8 and profiles/r2/README.md from profiles/r2/bench_*.json."""
-import json, os, re
+"""Regenerate the measured tables of README.md, DESIGN.md (section 8) and profiles/r3/README.md from profiles/r3/bench_*.json.
+
+Every generated block sits between the markers  <!-- r3:NAME:begin -->  and  <!-- r3:NAME:end -->  of its document; the
+prose around the blocks is written by hand.  Usage: python tools/fill_docs.py"""
+import json
+import os
+import re
+
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-L = lambda c: json.load(open(os.path.join(ROOT, "profiles", "r2", f"bench_{c}.json")))
-m, p, e, s, e3 = L("metrla"), L("pemsbay"), L("expytky"), L("syn8192"), L("expytky_bf16x3")
+R = os.path.join(ROOT, "profiles", "r3")
+L = lambda c: json.load(open(os.path.join(R, f"bench_{c}.json")))
+m, p, e, s = L("metrla"), L("pemsbay"), L("expytky"), L("syn8192")
+R2 = {"metrla": "9635 / 6.64 ms", "pemsbay": "5727 / 11.17 ms", "expytky": "4003 / 7.99 ms", "syn8192": "114 / 280 ms"}
+NAMES = [("metrla", "METR-LA N=207 B=64 T=12", m), ("pemsbay", "PEMS-BAY N=325 B=64 T=12", p),
+         ("expytky", "EXPY-TKY N=1843 B=32 T=6 H=32", e), ("syn8192", "SYN N=8192 B=32 T=12", s)]
 
-def sub_row(text, prefix, newrow):
-    lines = text.split("\n")
-    hit = [i for i, l in enumerate(lines) if l.startswith(prefix)]
-    assert len(hit) == 1, (prefix, len(hit))
-    lines[hit[0]] = newrow
-    return "\n".join(lines)
 
-# ---- README.md
-q = os.path.join(ROOT, "README.md"); t = open(q).read()
-t = sub_row(t, "| METR-LA-shaped", f"| METR-LA-shaped (N=207, B=64, T=12) | bf16x3 | {m['value']:.0f} | {m['ms_per_step']:.2f} | 8310 / 7.70 ms |")
-t = sub_row(t, "| PEMS-BAY-shaped", f"| PEMS-BAY-shaped (N=325, B=64) | bf16x3 | {p['value']:.0f} | {p['ms_per_step']:.2f} | 4170 / 15.4 ms |")
-t = sub_row(t, "| EXPY-TKY-shaped", f"| EXPY-TKY-shaped (N=1843, B=32, T=6, H=32) | bf16 | {e['value']:.0f} | {e['ms_per_step']:.2f} | 1510 / 21.2 ms (bf16x3; now {e3['value']:.0f} / {e3['ms_per_step']:.1f} ms in bf16x3) |")
-t = sub_row(t, "| synthetic N=8192", f"| synthetic N=8192 (B=32, T=12) | bf16 | {s['value']:.0f} | {s['ms_per_step']:.0f} | 28 / 1150 ms (bf16x3) |")
-t = re.sub(r"Propagation roofline \(algorithmic flops ÷ bf16 dense peak 2\.5 PF, HIP-event time inside real train steps\): N = 8192\n.*?of 8 TB/s\)\.",
-           f"Propagation roofline (algorithmic flops ÷ bf16 dense peak 2.5 PF, HIP-event time inside real train steps): N = 8192\n{s['roofline']['achieved']:.0f} TF = {100*s['roofline']['frac']:.1f} %, N = 1843 {e['roofline']['achieved']:.0f} TF = {100*e['roofline']['frac']:.1f} %; the small graphs are HBM-bound there (METR-LA {100*m['roofline']['frac']:.1f} %, PEMS-BAY {100*p['roofline']['frac']:.1f} % of 8 TB/s).", t, flags=re.S)
-open(q, "w").write(t)
-
-# ---- DESIGN.md section 8 table
-def fr(d):
+def roof(d):
     r = d["roofline"]
-    return (f"HBM-bound (AI {r['arithmetic_intensity']:.0f}): {r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s; {100*r['frac_of_mfma_peak']:.1f} % of MFMA peak" if r["bound"] == "hbm"
-            else f"MFMA-bound (AI {r['arithmetic_intensity']:.0f}): {r['achieved']:.0f} TF = **{100*r['frac']:.1f} %** of 2.5 PF")
-q = os.path.join(ROOT, "DESIGN.md"); t = open(q).read()
-t = sub_row(t, "  | METR-LA N=207 B=64 |", f"  | METR-LA N=207 B=64 | bf16x3 | {m['value']:.0f} | {m['ms_per_step']:.2f} | {m['kernel_launches_per_step']} | 8310 / 7.70 ms | {fr(m)} |")
-t = sub_row(t, "  | PEMS-BAY N=325 B=64 |", f"  | PEMS-BAY N=325 B=64 | bf16x3 | {p['value']:.0f} | {p['ms_per_step']:.2f} | {p['kernel_launches_per_step']} | 4170 / 15.4 ms | {fr(p)} |")
-t = sub_row(t, "  | EXPY-TKY N=1843 B=32 |", f"  | EXPY-TKY N=1843 B=32 | bf16 | {e['value']:.0f} | {e['ms_per_step']:.2f} | {e['kernel_launches_per_step']} | 1510 / 21.2 ms (bf16x3; now {e3['value']:.0f}) | {fr(e)} |")
-t = sub_row(t, "  | SYN N=8192 B=32 |", f"  | SYN N=8192 B=32 | bf16 | {s['value']:.0f} | {s['ms_per_step']:.0f} | {s['kernel_launches_per_step']} | 28 / 1140 ms (bf16x3) | {fr(s)} |")
-t = re.sub(r"is met at N = 8192\n  \(\d+ TF algorithmic = [\d.]+ %\) and NOT at N = 1843\n  \(\d+ TF = [\d.]+ %\)\.",
-           f"is met at N = 8192\n  ({s['roofline']['achieved']:.0f} TF algorithmic = {100*s['roofline']['frac']:.1f} %) and NOT at N = 1843\n  ({e['roofline']['achieved']:.0f} TF = {100*e['roofline']['frac']:.1f} %).", t)
-open(q, "w").write(t)
+    if r["bound"] == "hbm":
+        return f"HBM-bound (AI {r['arithmetic_intensity']:.0f} < 312): {r['achieved']:.0f} GB/s = {100 * r['frac']:.1f} % of 8 TB/s"
+    return f"MFMA-bound (AI {r['arithmetic_intensity']:.0f}): {r['achieved']:.0f} TF = **{100 * r['frac']:.1f} %** of 2.5 PF"
 
-# ---- profiles/r2/README.md: results table and role lines
-def row(lbl, d, r1):
+
+def traffic(d):
     r = d["roofline"]
-    ro = (f"{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s (HBM-bound, AI {r['arithmetic_intensity']:.0f} < 312)" if r["bound"] == "hbm"
-          else f"{r['achieved']:.0f} TF = {100*r['frac']:.1f} % of 2.5 PF (MFMA-bound, AI {r['arithmetic_intensity']:.0f})")
-    return f"| {lbl} | {d['dtype']} | **{d['value']:.0f}** | {d['ms_per_step']:.2f} | {d['kernel_launches_per_step']} | {r1} | {ro} | {r['traffic']/1e6:.1f} MB vs {r['alg_bytes_per_launch']/1e6:.1f} MB algorithmic |"
-roles = lambda d: ", ".join(f"{k} {v['ms_per_step']:.2f} ms ({v['launches_per_step']} × {v['avg_us']:.0f} µs, {v['alg_tflops']:.0f} TF)" for k, v in d["gemm_roles"].items())
-q = os.path.join(ROOT, "profiles", "r2", "README.md"); t = open(q).read()
-t = sub_row(t, "| METR-LA N=207 B=64 T=12 |", row("METR-LA N=207 B=64 T=12", m, "8310 / 7.70 ms"))
-t = sub_row(t, "| PEMS-BAY N=325 B=64 T=12 |", row("PEMS-BAY N=325 B=64 T=12", p, "4170 / 15.4 ms"))
-t = sub_row(t, "| EXPY-TKY N=1843 B=32 T=6 H=32 |", row("EXPY-TKY N=1843 B=32 T=6 H=32", e, "1510 / 21.2 ms (bf16x3)"))
-t = sub_row(t, "| SYN N=8192 B=32 T=12 |", row("SYN N=8192 B=32 T=12", s, "28 / 1140 ms (bf16x3)"))
-t = sub_row(t, "EXPY-TKY in the parity arithmetic", f"EXPY-TKY in the parity arithmetic (bf16x3, `bench_expytky_bf16x3.json`): {e3['value']:.0f} samples/s, {e3['ms_per_step']:.1f} ms/step.")
-t = sub_row(t, "* METR-LA: ", "* METR-LA: " + roles(m))
-t = sub_row(t, "* PEMS-BAY: ", "* PEMS-BAY: " + roles(p))
-t = sub_row(t, "* EXPY-TKY: ", "* EXPY-TKY: " + roles(e))
-t = sub_row(t, "* SYN-8192: ", "* SYN-8192: " + roles(s))
-cb = m["cpu_baseline"]
-t = re.sub(r"METR-LA [\d.]+ samples/s on \d+ BLAS threads / [\d.]+ on one thread \(the reference pins one\);\nPEMS-BAY [\d.]+ / [\d.]+; EXPY-TKY [\d.]+ / [\d.]+;\nSYN-8192 [\d.]+ / [\d.]+\.",
-           f"METR-LA {cb['value']:.1f} samples/s on {cb['cores']} BLAS threads / {cb['value_1thread']:.1f} on one thread (the reference pins one);\nPEMS-BAY {p['cpu_baseline']['value']:.1f} / {p['cpu_baseline']['value_1thread']:.1f}; EXPY-TKY {e['cpu_baseline']['value']:.2f} / {e['cpu_baseline']['value_1thread']:.2f};\nSYN-8192 {s['cpu_baseline']['value']:.4f} / {s['cpu_baseline']['value_1thread']:.4f}.", t)
-t = t.replace("inside one call.  The `bench_*.json` files below come from one call with the final library of the round, except\n`bench_pemsbay.json`, re-taken in a second call after a bookkeeping fix in `bench.py` (kernel name and hops per launch of\nthe N ≤ 352 fused propagation).",
-              "inside one call.  The `bench_*.json` files, kernel tables and traffic files below come from ONE call with the final\nlibrary of the round (`tools/fill_docs.py` copies their numbers into the three documents that quote them).")
-open(q, "w").write(t)
-print("docs refreshed:", m["value"], p["value"], e["value"], s["value"])
+    if not r.get("traffic"):
+        return "—"
+    return f"{r['traffic'] / 1e6:.1f} MB vs {r['alg_bytes_per_launch'] / 1e6:.1f} MB algorithmic ({r['traffic'] / r['alg_bytes_per_launch']:.2f}×)"
+
+
+def table(with_traffic):
+    head = "| config | arithmetic | samples/s | ms/step | launches/step | round 2 (samples/s / step) | forward propagation (dominant kernel), HIP-event time in real steps |"
+    sep = "|---|---|---|---|---|---|---|"
+    if with_traffic:
+        head += " PMC HBM bytes per launch |"
+        sep += "---|"
+    rows = [head, sep]
+    for key, lbl, d in NAMES:
+        row = f"| {lbl} | {d['dtype']} | **{d['value']:.0f}** | {d['ms_per_step']:.2f} | {d['kernel_launches_per_step']} | {R2[key]} | {roof(d)} |"
+        if with_traffic:
+            row += f" {traffic(d)} |"
+        rows.append(row)
+    return "\n".join(rows)
+
+
+def roles():
+    out = []
+    for key, lbl, d in NAMES:
+        out.append(f"* {lbl.split(' ')[0]}: " + ", ".join(
+            f"{k} {v['ms_per_step']:.2f} ms ({v['launches_per_step']} × {v['avg_us']:.0f} µs, {v['alg_tflops']:.0f} TF)" for k, v in d["gemm_roles"].items()))
+    return "\n".join(out)
+
+
+def cpu():
+    out = []
+    for key, lbl, d in NAMES:
+        c = d.get("cpu_baseline")
+        if not c:
+            continue
+        out.append(f"* {lbl.split(' ')[0]}: torch-CPU restatement {c['value']:.3g} samples/s on {c['cores']} threads, {c.get('value_1thread', float('nan')):.3g} on one thread"
+                   f" (what the reference pins); numpy port, one thread: {c.get('value_numpy_port_1thread', float('nan')):.3g}")
+    return "\n".join(out)
+
+
+def secondary():
+    sec = m.get("secondary")
+    if not sec:
+        return "(no secondary leg in bench_metrla.json)"
+    r = sec["roofline"]
+    return (f"`secondary` object of the default bench line (EXPY-TKY shape, bf16 mode, measured in the same run): {sec['value']:.0f} samples/s, "
+            f"{sec['ms_per_step']:.2f} ms/step, forward propagation {r['achieved']:.0f} TF = {100 * r['frac']:.1f} % of 2.5 PF.")
+
+
+BLOCKS = {
+    "table": lambda: table(False),
+    "table_traffic": lambda: table(True),
+    "roles": roles,
+    "cpu": cpu,
+    "secondary": secondary,
+}
+
+
+def fill(path):
+    t = open(path).read()
+    for name, fn in BLOCKS.items():
+        pat = re.compile(rf"(<!-- r3:{name}:begin -->\n).*?(<!-- r3:{name}:end -->)", re.S)
+        if pat.search(t):
+            t = pat.sub(lambda mo: mo.group(1) + fn() + "\n" + mo.group(2), t)
+    open(path, "w").write(t)
+
+
+for f in ("README.md", "DESIGN.md", os.path.join("profiles", "r3", "README.md")):
+    fill(os.path.join(ROOT, f))
+print("filled")
