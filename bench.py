@@ -32,7 +32,7 @@ CONFIGS = {
 SC_MEAN, SC_STD = 54.4, 19.5
 PEAK = {"f32": 157.3e12, "bf16x3": 2500e12, "bf16": 2500e12}
 HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: HBM3E 8 TB/s   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
-ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad"]
+ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad", "propagate_inputs"]
 
 
 def synth(cfg, B, seed, device):
@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the N=1843 propagation leg of the default run")
-    ap.add_argument("--roles", default="1,2,3,4,5,6", help="GEMM roles timed for gemm_roles (diagnostics)")
+    ap.add_argument("--roles", default="1,2,3,4,5,6,7", help="GEMM roles timed for gemm_roles (diagnostics); 7 = the hoisted once-per-stack\n                    input-channel products of the bf16 mode (absent in the other modes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -365,6 +365,8 @@ def main():
     if not args.no_roofline:
         for role in [int(r) for r in args.roles.split(",") if r]:
             ms, n, af, ef = time_role(tr, batch, role, 1)
+            if n == 0:
+                continue
             roles[ROLE_NAMES[role]] = dict(ms_per_step=round(ms, 4), launches_per_step=n,
                                            avg_us=round(1e3 * ms / max(n, 1), 3),
                                            alg_tflops=round(af / (ms * 1e-3) / 1e12, 2) if ms else 0,

@@ -204,7 +204,9 @@ int mcrn_last_launch_count(void);
  * bracketed by hipEventRecord on the stream it is launched on.  Roles (= last template argument
  * of mcrn::gemm_f32_kernel in rocprofv3 output): 1 propagation S x Z (model/MegaCRN.py:25),
  * 2 weight pool + GRU epilogue (:27,:43-47), 3 d-grad, 4 S^T propagation (backward),
- * 5 adjacency gradient, 6 weight gradient, 0 everything else.
+ * 5 adjacency gradient, 6 weight gradient, 0 everything else; 7 (timing only, bf16 mode): the
+ * once-per-stack products that propagate the input channels of every step (they run the role-1
+ * kernels on a narrow operand and are timed apart from the per-step propagation).
  * mcrn_prof_end synchronises on the recorded events and returns the summed kernel time, the number
  * of launches, their algorithmic flops (true channel counts) and executed flops. */
 int mcrn_prof_begin(int role);

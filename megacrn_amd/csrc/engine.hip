@@ -396,7 +396,7 @@ static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     }
     return best;
 }
-static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, hipStream_t st) {
+static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, hipStream_t st, int prof_role = -1) {
     ++g_launches;
     if (nsplit < 1) nsplit = 1;
     const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len, nsplit, role};
@@ -449,7 +449,7 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
             g_tuned_bf16[key] = cfg;
         } else cfg = bf16_cfg_prior(p, nsplit);
     }
-    const bool prof = g_prof.role == role && g_prof.n < Prof::MAXEV;
+    const bool prof = g_prof.role == (prof_role >= 0 ? prof_role : role) && g_prof.n < Prof::MAXEV;
     if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
     CK(launch_gemm_bf16(p, btr, cfg, nsplit, role, st));
     if (prof) {
@@ -539,7 +539,7 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     if (eff(64) != eff(32) || bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;    // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64);
     p.slab = (long long)p.M * ncp;
-    CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st));
+    CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st, PROF_ROLE_PROP_IN));
     const long long tot = (long long)u.nb * s.N * ncols;
     LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Z, Y,
            s.ZT, s.PS, s.ld, s.Cp, col0);
@@ -2280,7 +2280,7 @@ int mcrn_get_precision(void) { return g_precision; }
 int mcrn_set_side_stream(int enable) { g_use_side = enable != 0; return 0; }
 
 int mcrn_prof_begin(int role) {
-    if (role < 0 || role >= ROLE_COUNT) FAIL("prof: bad role %d", role);
+    if (role < 0 || role >= PROF_ROLE_COUNT) FAIL("prof: bad role %d", role);
     if (!g_prof.created) {
         for (int i = 0; i < 2 * Prof::MAXEV; ++i) CK(hipEventCreate(&g_prof.ev[i]));
         g_prof.created = true;

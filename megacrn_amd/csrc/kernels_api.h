@@ -30,7 +30,12 @@ enum Role {
     ROLE_PROPT = 4,   // S^T x dZ[g]  (backward propagation)
     ROLE_DS = 5,      // adjacency gradient  dZ x Z^T  (split-K)
     ROLE_WGRAD = 6,   // deferred weight gradient Z^T x dY (split-K)
-    ROLE_COUNT = 7
+    ROLE_COUNT = 7,
+    // timing-only id (mcrn_prof_begin): the hoisted once-per-stack products of the input channels in the bf16 mode.  They
+    // run the ROLE_PROP kernels (same epilogue) but are narrow (T*B*d columns, split-K): timed apart, so that role 1 is the
+    // per-step propagation alone
+    PROF_ROLE_PROP_IN = 7,
+    PROF_ROLE_COUNT = 8
 };
 
 struct GemmP {
