@@ -858,8 +858,9 @@ def test_packed_fp32_erratum_reproducer_and_guard():
 # interpreter per knob).  Each line = (environment, pytest -k selection that exercises the path it switches).
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env,select", [
-    ({"MCRN_BF16_CFG": "10"}, "bf16_mode"),                          # stream-K 256 x 256 (gemm_bf16_sk_kernel)
-    ({"MCRN_BF16_CFG": "11"}, "bf16_mode"),                          # stream-K 256 x 128
+    # (the stream-K runs skip the N = 8192 oracle case - 90 s of numpy each - and keep its full-size property test)
+    ({"MCRN_BF16_CFG": "10"}, "bf16_mode and not 8192-2-2"),         # stream-K 256 x 256 (gemm_bf16_sk_kernel)
+    ({"MCRN_BF16_CFG": "11"}, "bf16_mode and not 8192-2-2"),         # stream-K 256 x 128
     ({"MCRN_WGRAD_STREAM": "0"}, "model_train_step or large_graph"),  # weight gradient through the tiled GEMM + column sums
     ({"MCRN_DS_MERGE": "0"}, "model_train_step or kernel_variants"),  # one adjacency-gradient launch per AGCN call
     ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
