@@ -212,7 +212,7 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
 struct Side {
     hipStream_t st = nullptr;
     static const int NSLOT = 6;                  // plane sets: (update, gate) x NPAIR cells of the BPTT loop in flight
-    hipEvent_t ready[NSLOT], done[NSLOT], join, fork;
+    hipEvent_t ready[NSLOT], done[NSLOT], join, fork, mid;
     bool ok = false, pending[NSLOT] = {false, false, false, false, false, false}, any = false;
 };
 static Side g_side;
@@ -228,6 +228,7 @@ static int side_init() {
     }
     CK(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g_side.mid, hipEventDisableTiming));
     g_side.ok = true;
     return 0;
 }
@@ -2010,16 +2011,35 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                               bh ? P.dPin_e : nullptr, P.kin_e, 2 * t));
         }
     }
+    // Encoder weight / bias gradients: nothing below needs them, and they are HBM-streaming kernels while the adjacency
+    // backward below is MFMA work (bf16 mode: ~1 ms of full-chip products) or a chain of tiny launches (small graphs).  In
+    // the bf16 mode both go to the helper stream; on the small graphs the gate call's stays on the caller's stream (the
+    // helper stream is still finishing the last cell's adjacency gradient) and the update call's goes to the helper stream.
+    // The caller's stream then waits only for what the helper stream had BEFORE them (`mid`): the adjacency-gradient slabs.
+    static const bool tail_side_off = getenv("MCRN_TAIL_SIDE") && atoi(getenv("MCRN_TAIL_SIDE")) == 0;
+    const bool tail_side = g_use_side && !g_tuning && g_prof.role < 0 && !tail_side_off;
+    hipStream_t wg_st = st, wu_st = st;
+    float *part_g = P.part, *part_u = P.part;
+    if (tail_side) {
+        CKI(side_init());
+        CK(hipEventRecord(g_side.mid, g_side.st));
+        CK(hipEventRecord(g_side.fork, st));
+        CK(hipStreamWaitEvent(g_side.st, g_side.fork, 0));
+        wu_st = g_side.st; part_u = P.part2;
+        if (P.bf16) { wg_st = g_side.st; part_g = P.part2; }
+        g_side.any = true;
+    }
     int ns3 = 0;
-    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], wg_st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
+    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, wg_st, ns3, on3 ? g->enc_gate_b : nullptr));
+    if (!on3) CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, part_g, g->enc_gate_b, 0, wg_st));
     int ns4 = 0;
-    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], st, &ns4, &on4, lite ? P.Pb_e + PbS_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
-    CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, st, ns3, on3 ? g->enc_gate_b : nullptr));
-    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, st, ns4, on4 ? g->enc_update_b : nullptr));
-    if (!on3) CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, P.part, g->enc_gate_b, 0, st));
-    if (!on4) CKI(colsum(P.dU_e, H, Ti * R, H, P.part, g->enc_update_b, 0, st));
-    // ---- adjacency backward (all dS contributions are in the slabs once the helper stream is joined)
-    CKI(side_join(st));
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], wu_st, &ns4, &on4, lite ? P.Pb_e + PbS_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
+    CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, wu_st, ns4, on4 ? g->enc_update_b : nullptr));
+    if (!on4) CKI(colsum(P.dU_e, H, Ti * R, H, part_u, g->enc_update_b, 0, wu_st));
+    // ---- adjacency backward (all dS contributions are in the slabs once the helper stream's earlier work is joined)
+    if (tail_side) CK(hipStreamWaitEvent(st, g_side.mid, 0));
+    else CKI(side_join(st));
     if (P.bf16) {
         // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
