@@ -362,6 +362,9 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     (250, 320, 16, 8, 1, "8 row fragments (N > 224) with 96-column units: decoder B*Cp = 8960 columns = 140 64-column units > 128"),
     (40, 5, 24, 8, 2, "streaming d-grad with 3 k-steps and its partial staging round (O = 48); O = 24 falls back to the tiled GEMM"),
     (207, 3, 8, 8, 2, "streaming d-grad with a single k-step (O = 16); update O = 8 falls back"),
+    (40, 5, 40, 40, 2, "two-half streaming d-grad <5,2>: decoder gate O = 160 (encoder gate O = 80: <5,1>)"),
+    (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192"),
+    (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment"),
 ])
 def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
     """Shapes chosen to reach kernel variants the golden cases do not (see `why`): forward and every parameter
