@@ -365,11 +365,12 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     (40, 5, 40, 40, 2, "two-half streaming d-grad <5,2>: decoder gate O = 160 (encoder gate O = 80: <5,1>)"),
     (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192"),
     (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment"),
+    (45, 6, 32, 32, 2, "cheb_k=2: streaming weight pool with 2 propagated planes (wp_stream_kernel<2|4, 2, ..>), fp32 planes"),
 ])
 def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
     """Shapes chosen to reach kernel variants the golden cases do not (see `why`): forward and every parameter
     gradient of a train-mode step vs the float64 oracle."""
-    M, cheb_k = 4, 3
+    M, cheb_k = 4, (2 if why.startswith("cheb_k=2") else 3)
     P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=5)
     rng = np.random.default_rng(9)
     for k in P:
@@ -697,6 +698,7 @@ BF16_TOL = 2e-2        # stated tolerance of the mode (max-norm relative, like T
 @pytest.mark.parametrize("N,B,T,H,M,D,cheb_k", [
     (300, 3, 3, 12, 6, 8, 3),        # odd batch: plane rows padded to 8 channels; K tail of 300 = 4 x 64 + 44
     (261, 4, 2, 12, 6, 8, 2),        # cheb_k = 2: two stacked blocks, no T2
+    (261, 8, 2, 32, 6, 32, 2),       # cheb_k = 2 at a width the streaming weight pool takes: bf16-resident planes, 2 of them
     (1843, 4, 6, 32, 10, 32, 3),     # EXPY-TKY geometry at a reduced batch
     (1843, 8, 3, 32, 10, 32, 3),     # ... at a batch the hoisted backward takes (B * input channels % 8 == 0): packed state-channel
                                      #     planes, stack-wide input operands, the go-symbol product of the non-teacher steps
