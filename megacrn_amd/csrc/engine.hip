@@ -520,7 +520,7 @@ static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, ui
 // Z[t] and Y[t] (gate and candidate input share their input channels, model/MegaCRN.py:42,45).
 static const int HOIST_MAX_SPLIT = 8;
 static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, uint16_t* xin_b, float* xin_t,
-                        hipStream_t st) {
+                        hipStream_t st, float* Xp = nullptr /* compact destination [T][nb][R][4] (k_scatter_compact) instead of the planes */) {
     if (!s.hoist || w <= 0 || T <= 0) return 0;
     const int ncols = T * s.B * w;
     const int ncp = ncols < 8 ? 8 : (ncols + 7) & ~7;
@@ -541,6 +541,12 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     const int nsp = eff(64);
     p.slab = (long long)p.M * ncp;
     CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st, PROF_ROLE_PROP_IN));
+    if (Xp) {
+        const long long rows = (long long)T * u.nb * s.R;
+        LAUNCH(k_scatter_compact, dim3(cdiv(rows, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Xp,
+               (long long)u.nb * s.R * 4, col0 - s.H, w == s.d ? 1 : 0);
+        return 0;
+    }
     const long long tot = (long long)u.nb * s.N * ncols;
     LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Z, Y,
            s.ZT, s.PS, s.ld, s.Cp, col0);
@@ -979,7 +985,8 @@ static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* d
 }
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
                       int O, float* slabs, hipStream_t st, int* nslab, bool* ones = nullptr,
-                      const uint16_t* Xb = nullptr /* bf16-resident planes of these calls */, long long xb_step = 0, long long xb_plane = 0) {
+                      const uint16_t* Xb = nullptr /* bf16-resident planes of these calls */, long long xb_step = 0, long long xb_plane = 0,
+                      const float* Xc = nullptr /* compact input channels of planes 1 .. nb, [T][nb][R][4] */) {
     // ones != null: the caller wants the column sums of dY (bias gradient) as row G*Cp of the slabs when the streaming
     // kernel runs (*ones = true), and computes them itself otherwise
     if (ones) *ones = false;
@@ -989,6 +996,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
         WgradP q;
         memset(&q, 0, sizeof q);
         q.Xb = Xb; q.xb_step = xb_step; q.xb_plane = xb_plane; q.H = s.H;
+        q.Xc = Xb ? Xc : nullptr; q.xc_plane = s.R * 4; q.xc_step = (long long)(s.G - 1) * s.R * 4;
         q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
         q.dY = dYall; q.O = O; q.slabs = slabs; q.ones = ones ? 1 : 0;
         if (ones) *ones = true;
@@ -1068,9 +1076,10 @@ struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if
 // streaming weight pool on bf16-resident planes (wp_stream.h) with the library's profiling hooks
 static int wp_stream(const Shp& s, const Sup& u, const float* Z, const uint16_t* Pb, const uint4* img, const float* bias, int epi,
                      float* out, float* out2, long long out2_ld, uint16_t* out2b, const float* hsrc, long long hsrc_ld,
-                     const float* zr, hipStream_t st) {
+                     const float* zr, hipStream_t st, const float* xc = nullptr) {
     WpP q;
     memset(&q, 0, sizeof q);
+    q.Xc = xc; q.xc_plane = s.R * 4;
     q.Z = Z; q.Pb = Pb; q.PS = s.PS; q.PSh = s.R * s.H; q.R = s.R; q.Cp = s.Cp; q.H = s.H; q.d = s.d; q.nbp = u.nb;
     q.O = epi == WP_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
     q.out = out; q.out2 = out2; q.out2_ld = out2_ld; q.out2b = out2b; q.hsrc = hsrc; q.hsrc_ld = hsrc_ld; q.zr = zr;
@@ -1084,13 +1093,14 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
                          const CellW& w, float* hnext, long long hnext_ld, hipStream_t st, uint16_t* x0b = nullptr,
                          uint16_t* x0c = nullptr, uint16_t* Pb = nullptr /* this cell's bf16 planes: gate call, update call */,
                          bool packed = false /* x0b of the gate call was emitted by the previous cell's epilogue */,
-                         uint16_t* x0b_next = nullptr /* where this cell's new state goes as the next gate call's operand */) {
+                         uint16_t* x0b_next = nullptr /* where this cell's new state goes as the next gate call's operand */,
+                         const float* xc = nullptr /* this step's compact propagated input channels (both calls share them) */) {
     if (g_prop_bf16 && s.lite && Pb && x0b && w.wp_g && w.wp_u) {
         const long long PbS = (long long)u.nb * s.N * s.ldh;
         CKI(prop_fwd(s, u, Z, st, x0b, x0c, Pb, packed));
-        CKI(wp_stream(s, u, Z, Pb, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, x0b + s.PSb, nullptr, 0, nullptr, st));
+        CKI(wp_stream(s, u, Z, Pb, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, x0b + s.PSb, nullptr, 0, nullptr, st, xc));
         CKI(prop_fwd(s, u, Y, st, x0b + s.PSb, x0c ? x0c + s.PSb : nullptr, Pb + PbS, true));
-        CKI(wp_stream(s, u, Y, Pb + PbS, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, x0b_next, Z, s.Cp, zr, st));
+        CKI(wp_stream(s, u, Y, Pb + PbS, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, x0b_next, Z, s.Cp, zr, st, xc));
         return 0;
     }
     static const int fused_maxh = getenv("MCRN_AGCN_FUSED_MAXH") ? atoi(getenv("MCRN_AGCN_FUSED_MAXH")) : 1 << 30;   // A/B: fuse cells up to this width only
@@ -1380,6 +1390,7 @@ struct ModelPlan {
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     uint16_t* xin_b; float* xin_t;   // hoisted input channels: packed bf16 operand [Kp][ncp] and its fp32 product [nb*N][ncp]
     // hoisted backward of the bf16 mode: stack-wide bf16 operands of the adjacency gradient's input part, go-gradient scratch
+    float *Xp_e, *Xp_d;              // compact propagated input channels of the stacks, [T][nb][R][4] (d <= 4; k_scatter_compact)
     bool bwd_hoist; long long kin_e, kin_d;
     uint16_t *dPin_e, *dPin_d, *xin_c; float* go_tmp;
     float* xin_f;                    // small graphs, fused AGCN kernel: scratch plane set [5][N][ncp] of the hoisted input channels
@@ -1476,12 +1487,18 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
     P.xin_b = nullptr; P.xin_t = nullptr;
     P.Pb_e = P.Pb_d = nullptr;
+    P.Xp_e = P.Xp_d = nullptr;
     P.bwd_hoist = false; P.kin_e = P.kin_d = 0; P.dPin_e = P.dPin_d = P.xin_c = nullptr; P.go_tmp = nullptr;
     for (int i = 0; i < 4; ++i) P.wpimg[i] = nullptr;
     if (P.bf16) {
         if (P.se.lite && P.sd.lite) {
             P.Pb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * N * P.se.ldh + 64);     // (+ slack: 16-byte reads of 8-byte quads)
             P.Pb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * N * P.sd.ldh + 64);
+            static const bool xp_off = getenv("MCRN_BF16_COMPACT_IN") && atoi(getenv("MCRN_BF16_COMPACT_IN")) == 0;
+            if (!xp_off && d->input_dim <= 4 && od + yd <= 4) {
+                P.Xp_e = b.take<float>((size_t)d->T_in * P.nb * R * 4 + 64);
+                P.Xp_d = b.take<float>((size_t)d->T_out * P.nb * R * 4 + 64);
+            }
             static const bool bh_off = getenv("MCRN_BF16_BWD_HOIST") && atoi(getenv("MCRN_BF16_BWD_HOIST")) == 0;
             const int bwe = B * d->input_dim, bwd_ = B * (od + yd);
             P.bwd_hoist = !bh_off && (bwe % 8) == 0 && (bwd_ % 8) == 0;
@@ -1792,8 +1809,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
         CK(hipStreamWaitEvent(st, g_side.join, 0));
     }
     if (P.bf16) {   // t-invariant part of the propagation: the input channels of every step, once per stack
-        CKI(hoist_inputs(se, u, P.Zenc, P.Yenc, Ti, H, din, P.xin_b, P.xin_t, st));
-        CKI(hoist_inputs(sd, u, P.Zdec, P.Ydec, To, Hd, od + yd, P.xin_b, P.xin_t, st));
+        CKI(hoist_inputs(se, u, P.Zenc, P.Yenc, Ti, H, din, P.xin_b, P.xin_t, st, P.Xp_e));
+        CKI(hoist_inputs(sd, u, P.Zdec, P.Ydec, To, Hd, od + yd, P.xin_b, P.xin_t, st, P.Xp_d));
     } else if (se.fused) {
         CKI(hoist_inputs_small(se, u, P.Zenc, P.Yenc, Ti, H, se.Cp - H, P.xin_f, st));
         CKI(hoist_inputs_small(sd, u, P.Zdec, P.Ydec, To, Hd, sd.Cp - Hd, P.xin_f, st));
@@ -1806,7 +1823,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                           we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PSb : nullptr,
                           P.bf16 ? P.x0c_e + (long long)2 * t * se.PSb : nullptr,
                           lite ? P.Pb_e + (long long)2 * t * PbS_e : nullptr, t > 0,
-                          lite && t + 1 < Ti ? P.x0b_e + (long long)2 * (t + 1) * se.PSb : nullptr));
+                          lite && t + 1 < Ti ? P.x0b_e + (long long)2 * (t + 1) * se.PSb : nullptr,
+                          P.Xp_e ? P.Xp_e + (long long)t * P.nb * R * 4 : nullptr));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
                           P.dsc, P.ind_rows, P.Zdec, sd.Cp, h_att, query, pos, neg, nullptr, st));
@@ -1819,7 +1837,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                           P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PSb : nullptr,
                           P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr,
                           lite ? P.Pb_d + (long long)2 * t * PbS_d : nullptr, t > 0,
-                          lite && t + 1 < To ? P.x0b_d + (long long)2 * (t + 1) * sd.PSb : nullptr));
+                          lite && t + 1 < To ? P.x0b_d + (long long)2 * (t + 1) * sd.PSb : nullptr,
+                          P.Xp_d ? P.Xp_d + (long long)t * P.nb * R * 4 : nullptr));
         const bool last = t + 1 == To;
         const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;
         LAUNCH(k_proj_fwd, dim3(cdiv(R, 4) < 2048 ? cdiv(R, 4) : 2048), dim3(256), 0, st, (const float*)Zn,
@@ -1827,7 +1846,8 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                (long long)To * N * od, (long long)od, last ? (float*)nullptr : Zn,
                last ? (float*)nullptr : P.Ydec + (t + 1) * sd.ZT, (long long)sd.Cp, Hd, lab);
         // go = proj(h') was not known when the decoder's input channels were hoisted: propagate this one channel block now
-        if (P.bf16 && !last && !lab) CKI(hoist_inputs(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_b, P.xin_t, st));
+        if (P.bf16 && !last && !lab) CKI(hoist_inputs(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_b, P.xin_t, st,
+                                                     P.Xp_d ? P.Xp_d + (long long)(t + 1) * P.nb * R * 4 : nullptr));
         if (!P.bf16 && sd.fused && !last && !lab) CKI(hoist_inputs_small(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_f, st));
     }
     return 0;
@@ -1944,9 +1964,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     bool on1 = false, on2 = false, on3 = false, on4 = false;
     const bool lite = P.bf16 && P.Pb_e != nullptr;
     const long long PbS_e = (long long)P.nb * N * se.ldh, PbS_d = (long long)P.nb * N * sd.ldh;
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d));
     int ns2 = 0;
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d));
     // hoisted backward, adjacency gradient of one cell stack (K-concatenated over every AGCN call); with MCRN_BF16_DS_SIDE=1 the
     // decoder's runs on the helper stream behind its weight gradients and overlaps the encoder BPTT; the encoder's accumulates
     // into the same dA after the join
@@ -2030,11 +2050,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         g_side.any = true;
     }
     int ns3 = 0;
-    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], wg_st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
+    CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], wg_st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh, P.Xp_e));
     CKI(wunprep(g->enc_gate_w, P.dWs[0], se, 2 * H, wg_st, ns3, on3 ? g->enc_gate_b : nullptr));
     if (!on3) CKI(colsum(P.dG_e, 2 * H, Ti * R, 2 * H, part_g, g->enc_gate_b, 0, wg_st));
     int ns4 = 0;
-    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], wu_st, &ns4, &on4, lite ? P.Pb_e + PbS_e : nullptr, 2 * PbS_e, (long long)N * se.ldh));
+    CKI(agcn_wgrad(se, P.Yenc, se.ZT, Ti, P.dU_e, H, P.dWs[1], wu_st, &ns4, &on4, lite ? P.Pb_e + PbS_e : nullptr, 2 * PbS_e, (long long)N * se.ldh, P.Xp_e));
     CKI(wunprep(g->enc_update_w, P.dWs[1], se, H, wu_st, ns4, on4 ? g->enc_update_b : nullptr));
     if (!on4) CKI(colsum(P.dU_e, H, Ti * R, H, part_u, g->enc_update_b, 0, wu_st));
     // ---- adjacency backward (all dS contributions are in the slabs once the helper stream's earlier work is joined)

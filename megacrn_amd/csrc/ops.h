@@ -1001,6 +1001,33 @@ __global__ void k_scatter_cols(const float* __restrict__ tmp, int ldt, int nspli
     if (Y) Y[o] = v;
 }
 
+// The same sums into the COMPACT input array of the bf16-resident mode (the fp32 planes 1 .. nb of a plane set hold nothing but
+// their d <= 4 input channels there; scattering them at a Cp-float stride is a 4-byte write into a separate memory line each:
+// 82 + 117 us per EXPY-TKY step):  Xp[t][blk][r = n*B + b][4]  = channels c0 .. c0 + w of that row, one 16-byte row per
+// (step, plane, row), read by wp_stream (input group) and wgrad_stream (the quad at channel H).
+// full: w covers all d channels of the stack -> the whole float4 is written (zeros behind d); else only channels c0 .. c0 + w.
+__global__ void k_scatter_compact(const float* __restrict__ tmp, int ldt, int nsplit, long long slab, int nb, int N, int B, int w, int T,
+                                  float* __restrict__ Xp, long long xp_t, int c0, int full) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (t, blk, n, b): consecutive threads = consecutive rows
+    const long long R = (long long)N * B;
+    if (i >= (long long)T * nb * R) return;
+    const int b = (int)(i % B);
+    long long q = i / B;
+    const int n = (int)(q % N); q /= N;
+    const int blk = (int)(q % nb), t = (int)(q / nb);
+    const long long rowi = (long long)blk * N + n;
+    const float* __restrict__ src = tmp + rowi * ldt + ((long long)t * B + b) * w;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < w; ++j) {
+        float a = src[j];
+        for (int z = 1; z < nsplit; ++z) a += src[z * slab + j];               // split-K partial products, fixed order
+        v[c0 + j] = a;
+    }
+    float* __restrict__ dst = Xp + (long long)t * xp_t + ((long long)blk * R + (long long)n * B + b) * 4;
+    if (full) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int j = 0; j < w; ++j) dst[c0 + j] = v[c0 + j];
+}
+
 // colsum[c] = (N / nsamp) * sum over nsamp evenly spaced rows of X[row][c]: an ESTIMATE of the column sums over all N
 // rows.  The centring above is exact for ANY vector subtracted from every row (it only has to be the same vector for
 // all rows); what matters numerically is that the bulk of the common component is gone, so a 64-row sample replaces

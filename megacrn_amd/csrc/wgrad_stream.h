@@ -105,6 +105,11 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const WgradP p) {
         if (isbA[j]) {
             ptrA[j] = reinterpret_cast<const unsigned char*>(p.Xb + (long long)t * p.xb_step + (long long)(g - 1) * p.xb_plane + r0 * p.H + c);
             strA[j] = p.H * 2;
+        } else if (p.Xc != nullptr && g >= 1 && c >= p.H && okA[j]) {
+            // compact input channels: the quad at channel H is one 16-byte row; the pad quads behind it are zero (masked: any valid address)
+            ptrA[j] = reinterpret_cast<const unsigned char*>(p.Xc + (long long)t * p.xc_step + (long long)(g - 1) * p.xc_plane + r0 * 4);
+            strA[j] = 16;
+            if (c != p.H) okA[j] = false;
         } else {
             ptrA[j] = reinterpret_cast<const unsigned char*>(p.X + (long long)t * p.step_stride + (long long)g * p.PS + r0 * p.Cp + c);
             strA[j] = p.Cp * 4;

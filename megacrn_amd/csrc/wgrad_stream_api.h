@@ -26,6 +26,10 @@ struct WgradP {
     const unsigned short* Xb;
     long long xb_step, xb_plane;
     int H;
+    // ... and, when Xc != null, their input channels come from the compact array  Xc[t * xc_step + (g - 1) * xc_plane + r * 4 + 0..3]
+    // (k_scatter_compact: d <= 4 channels + zeros): the quad at channel H of a plane g >= 1 is one row of it, later quads are zero
+    const float* Xc;
+    long long xc_step, xc_plane;
 };
 
 // shapes the kernel takes: O <= 512, O % 4 == 0, Cp % 4 == 0, 16-byte aligned bases

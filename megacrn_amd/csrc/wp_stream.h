@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void wp_stream_kernel(const WpP p) {
                 const int q = 8 * kq + i;
                 const int qc = q < nin ? q : 0;
                 const int gg = qc / p.d, j = qc - gg * p.d;
-                const float x = p.Z[(long long)gg * p.PS + ra * p.Cp + H + j];
+                const float* __restrict__ src = (p.Xc && gg >= 1) ? p.Xc + (long long)(gg - 1) * p.xc_plane + ra * 4 + j
+                                                                  : p.Z + (long long)gg * p.PS + ra * p.Cp + H + j;
+                const float x = *src;
                 ain[i] = q < nin ? x : 0.f;                                 // (a select on the loaded value, not a branch)
             }
         } else if (PBF16 && g > 0) {

@@ -29,6 +29,8 @@ struct WpP {
     const float* hsrc;        // UPDATE: previous state h[r*hsrc_ld + c]   (GATE reads it from plane 0 of Z)
     long long hsrc_ld;
     const float* zr;          // UPDATE: the gate call's `out`
+    const float* Xc;          // nullable: compact input channels of planes 1 .. nbp, [nbp][R][4] (k_scatter_compact) - then Z is read
+    long long xc_plane;       //           for plane 0 only; stride between planes in floats (= 4 R)
 };
 
 bool wp_stream_ok(int H, int d, int nbp, int O);

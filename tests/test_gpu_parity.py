@@ -874,6 +874,7 @@ def test_packed_fp32_erratum_reproducer_and_guard():
     ({"MCRN_HOIST": "0"}, "bf16_mode_train and 1843"),               # bf16 mode without hoisting (all B*Cp columns per step)
     ({"MCRN_BF16_PLANES": "0"}, "bf16_mode_train and 1843"),         # hoisted propagation into fp32 planes (no bf16-resident planes)
     ({"MCRN_BF16_BWD_HOIST": "0"}, "bf16_mode_train and 1843"),      # hoisted forward, full-width backward
+    ({"MCRN_BF16_COMPACT_IN": "0"}, "bf16_mode_train and 1843"),     # propagated input channels scattered into the fp32 planes (no compact array)
 ])
 def test_alternative_paths_keep_parity(env, select):
     import subprocess
