@@ -384,7 +384,10 @@ def main():
     if rank == 0 and world == 1 and args.config == "metrla" and not args.no_secondary and not args.no_roofline:
         del tr
         torch.cuda.empty_cache()
-        secondary = secondary_leg(device)
+        try:
+            secondary = secondary_leg(device)
+        except Exception as e:                      # the headline line must not depend on the extra leg
+            secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
