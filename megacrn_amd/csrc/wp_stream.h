@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "wp_stream_api.h"
 
 namespace mcrn {
@@ -283,7 +284,10 @@ static inline int wp_pick_nbf(int H, int O, long long R) {
     for (int nbf = 4; nbf >= 1; nbf >>= 1) {
         if (O % (32 * nbf)) continue;
         best = nbf;
-        if (rb * (O / (32 * nbf)) >= 160) break;
+        // (measured, METR-LA: 104 row blocks -> 208 workgroups per launch 6.26 ms/step, 416 6.12, 832 6.31; PEMS-BAY and
+        //  EXPY-TKY unchanged between 160 and 300: with two workgroups per CU one's stage waits hide behind the other's MFMAs)
+        static const int minwg = getenv("MCRN_WP_MINWG") ? atoi(getenv("MCRN_WP_MINWG")) : 300;
+        if (rb * (O / (32 * nbf)) >= minwg) break;
     }
     return best;
 }
