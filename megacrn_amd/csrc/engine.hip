@@ -214,6 +214,7 @@ struct Side {
     static const int NSLOT = 6;                  // plane sets: (update, gate) x NPAIR cells of the BPTT loop in flight
     hipEvent_t ready[NSLOT], done[NSLOT], join, fork, mid;
     bool ok = false, pending[NSLOT] = {false, false, false, false, false, false}, any = false;
+    bool paired[NSLOT] = {false, false, false, false, false, false};   // done[buf] and done[buf ^ 1] mark the SAME launch (merged per cell)
 };
 static Side g_side;
 static bool g_use_side = true;
@@ -237,6 +238,10 @@ static int side_guard(int buf, hipStream_t st) {
     if (g_side.ok && g_side.pending[buf]) {
         CK(hipStreamWaitEvent(st, g_side.done[buf], 0));
         g_side.pending[buf] = false;
+        // one merged launch read both plane sets of its cell: its completion frees the sibling set as well, and every
+        // event wait is a barrier packet of ~6 us in the caller's queue (profiles/r3/experiments.md)
+        static const bool pair_off = getenv("MCRN_PAIR_GUARD") && atoi(getenv("MCRN_PAIR_GUARD")) == 0;
+        if (g_side.paired[buf] && !pair_off) g_side.pending[buf ^ 1] = false;
     }
     return 0;
 }
@@ -909,6 +914,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                     const int bi = cell_ds ? (buf & ~1) + i : buf;
                     CK(hipEventRecord(g_side.done[bi], g_side.st));
                     g_side.pending[bi] = true;
+                    g_side.paired[bi] = cell_ds != nullptr;
                 }
                 g_side.any = true;
             }
@@ -934,7 +940,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
             CKI(gemm(p, true, true, u.nslab, ROLE_DS, g_side.st));
             CK(hipEventRecord(g_side.done[buf], g_side.st));
-            g_side.pending[buf] = true; g_side.any = true;
+            g_side.pending[buf] = true; g_side.paired[buf] = false; g_side.any = true;
         } else {
             CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
         }
