@@ -17,9 +17,8 @@ for name in (sys.argv[1:] or ["metrla"]):
     cfg = bench.CONFIGS[name]
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
-    model = megacrn_amd.MegaCRN(cfg["N"], 1, 1, cfg["T"], cfg["H"], mem_num=cfg["M"], mem_dim=cfg["D"]).to(dev).train()
-    tr = FlatTrainer(model, scaler_mean=54.4, scaler_std=19.5)
-    x, yc, y = bench.synth(cfg, cfg["B"], 1234, dev)
+    prec = "bf16" if cfg["N"] >= 1024 else "bf16x3"           # the arithmetic bench.py runs the configuration in
+    tr, (x, yc, y) = bench.make_trainer(name, cfg["B"], prec, dev, 0)
     for _ in range(20):
         tr.train_step(x, yc, y)
     torch.cuda.synchronize()
