@@ -660,6 +660,7 @@ static int ds_bf16_in(const Shp& s, const Sup& u, const uint16_t* dPin, const ui
 // hoisted backward, a decoder cell whose go symbol was the projection of the previous step (not teacher-forced): the input
 // channels of its planes 1 .. nb carry gradient for that symbol,  d go += sum_g T_g^T dP_g[:, input columns] ; both calls of the
 // cell (adjacent column blocks of the stack-wide operand dPin) in one product, added to the go columns of the two planes 0
+static const int GO_MAX_SPLIT = 16;
 static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long long kin, int call0, float* tmp, float* dQ0, float* dP0,
                         int od, hipStream_t st) {
     const int bw = s.B * s.d;                                       // columns of one call
@@ -668,10 +669,21 @@ static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long l
     p.B = dPin + (long long)call0 * bw; p.ldb = kin; p.N = 2 * bw;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = (long long)s.N * kin;
     p.C = tmp; p.cm = rm_plain(2 * bw);
-    CKI(bf16_gemm(p, true, 1, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * 2.0 * bw, st));
+    // N x 2*B*d output (8 tiles of 256 x 128 at N = 1843) over K = nb*N: split K so that the launch fills the chip (88 us unsplit)
+    const long long tiles = (long long)cdiv(p.M, 256) * cdiv(p.N, 128);
+    int nsplit = (int)((240 + tiles / 2) / tiles);
+    nsplit = nsplit < 1 ? 1 : (nsplit > GO_MAX_SPLIT ? GO_MAX_SPLIT : nsplit);
+    // splits the launcher really makes for a K tile of 64 and of 32 (bf16_split_plan): the consumer below must know the count
+    // whatever tile the tuner picks, so the request is lowered until both depths round it the same way
+    auto eff = [&](int bk, int want) { const int kt = u.nb * cdiv(s.N, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    while (nsplit > 1 && eff(64, nsplit) != eff(32, nsplit)) --nsplit;
+    if (bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;                             // (a forced stream-K configuration ignores the split)
+    const int nsp = eff(64, nsplit);
+    p.slab = (long long)s.N * 2 * bw;
+    CKI(bf16_gemm(p, true, nsplit, ROLE_PROPT, (double)u.nb * 2.0 * (double)s.N * s.N * 2.0 * bw, st));
     const long long tot = (long long)s.N * s.B * od;
-    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, 0, s.N, s.B, s.d, od, dQ0, s.ld, s.Cp, s.H);
-    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, bw, s.N, s.B, s.d, od, dP0, s.ld, s.Cp, s.H);
+    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, 0, nsp, p.slab, s.N, s.B, s.d, od, dQ0, s.ld, s.Cp, s.H);
+    LAUNCH(k_scatter_add_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)tmp, 2 * bw, bw, nsp, p.slab, s.N, s.B, s.d, od, dP0, s.ld, s.Cp, s.H);
     return 0;
 }
 
@@ -1514,7 +1526,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
                 P.dPin_e = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_e);
                 P.dPin_d = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_d);
                 P.xin_c = b.take<uint16_t>((size_t)(N + 64) * (P.kin_e > P.kin_d ? P.kin_e : P.kin_d));
-                P.go_tmp = b.take<float>((size_t)N * 2 * bwd_ + 64);
+                P.go_tmp = b.take<float>((size_t)GO_MAX_SPLIT * N * 2 * bwd_ + 64);
             }
         }
         {

@@ -957,7 +957,8 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
     dst[(long long)blockIdx.y * dst_y + ((long long)row * ldo + dcol) / 8] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
 }
 // dst[n][b*Cp + col0 + j] += tmp[n][coff + b*w + j]   (j < wuse <= w): the go-symbol share of a propagated input gradient
-__global__ void k_scatter_add_cols(const float* __restrict__ tmp, int ldt, int coff, int N, int B, int w, int wuse,
+// (tmp: the sum of `nsplit` split-K partial products `slab` floats apart, added in a fixed order)
+__global__ void k_scatter_add_cols(const float* __restrict__ tmp, int ldt, int coff, int nsplit, long long slab, int N, int B, int w, int wuse,
                                    float* __restrict__ dst, long long ld, int Cp, int col0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * B * wuse) return;
@@ -965,7 +966,10 @@ __global__ void k_scatter_add_cols(const float* __restrict__ tmp, int ldt, int c
     const long long q = i / wuse;
     const int b = (int)(q % B);
     const long long n = q / B;
-    dst[n * ld + (long long)b * Cp + col0 + j] += tmp[n * ldt + coff + b * w + j];
+    const float* __restrict__ src = tmp + n * ldt + coff + b * w + j;
+    float v = src[0];
+    for (int z = 1; z < nsplit; ++z) v += src[z * slab];
+    dst[n * ld + (long long)b * Cp + col0 + j] += v;
 }
 // fp32 variant for the small graphs (bf16x3 mode: the hoisted product runs on the fused two-hop kernel of prop_small.h):
 //   dst[n][(t*B + b)*w + j] = src[t*src_t + n*ld + b*Cp + col0 + j]      columns up to ldo are zero
