@@ -67,7 +67,7 @@ def pmc_traffic(config_name, dtype, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 per
     MI355X_MICROARCH.md).  None when no profile of this config is committed."""
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"traffic_{config_name}.json")
         if os.path.exists(path):
             break
@@ -76,8 +76,8 @@ def pmc_traffic(config_name, dtype, N):
     d = json.load(open(path))
     if dtype == "bf16":
         keys = ("true, 1>",)                      # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
-    elif N <= 352 and dtype == "bf16x3":            # fused two-hop kernels (prop_small.h: PROP2_MAX_N)
-        keys = ("prop2_fwd_kernel",)
+    elif N <= 352 and dtype == "bf16x3":            # matrix-form single-hop kernel (prop_mform.h) / fused two-hop kernels (prop_small.h)
+        keys = ("prop1_kernel",) if mform_on() else ("prop2_fwd_kernel",)
     else:
         keys = ("true, false, 1>",)               # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
     tot = n = 0
@@ -202,10 +202,52 @@ def self_launch(args):
     return subprocess.call(launch_cmd(args.gpus, port, sys.argv[1:]), env=launch_env())
 
 
+def mform_on():
+    return os.environ.get("MCRN_MFORM", "1") != "0"
+
+
 def prop_kernel_name(cfg, dtype):
+    small = cfg["N"] <= 352 and dtype == "bf16x3"
     return ("mcrn::gemm_bf16(_pp)_kernel<BM,BN,..,BTR=true,ROLE=1> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
-            "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if cfg["N"] <= 352 and dtype == "bf16x3" else
+            "mcrn::prop1_kernel<NF,CT,STREAM> (matrix form: [S1; 2 S1 S1 - I; S2; 2 S2 S2 - I] x plane 0, one single-hop launch)" if small and mform_on() else
+            "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if small else
             "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
+
+
+NO_TEACHER_STEP = 10 ** 6     # batches_seen at which cl / (cl + exp(step / cl)) is 0 (model/MegaCRN.py:146-147): no step teacher-forced
+
+
+def regime_legs(tr, batch, B, steps, warmup, sync):
+    """What training mostly runs (model/MegaCRN.py:146-147,188-191: the teacher-forcing probability is 0.5 at batches_seen =
+    15 200 and ~0 beyond 30 000, while the headline steps start at batches_seen = 0 and are fully teacher-forced) and the
+    evaluation forward of the reference's val / test passes (model/traintest_MegaCRN.py:50-99): same batch, same process."""
+    x, ycov, y = batch
+    saved = tr.batches_seen
+    tr.batches_seen = NO_TEACHER_STEP
+    for _ in range(warmup):
+        tr.train_step(x, ycov, y)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(x, ycov, y)
+    sync()
+    dt_nt = time.perf_counter() - t0
+    tr.batches_seen = saved
+    m = tr.model
+    m.eval()
+    with torch.no_grad():
+        for _ in range(warmup):
+            m(x, ycov)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x, ycov)
+        sync()
+        dt_ev = time.perf_counter() - t0
+    m.train()
+    return {"value_no_teacher": round(B * steps / dt_nt, 2), "ms_per_step_no_teacher": round(1e3 * dt_nt / steps, 4),
+            "eval_samples_per_s": round(B * steps / dt_ev, 2), "ms_per_eval_forward": round(1e3 * dt_ev / steps, 4),
+            "regime_steps": steps}
 
 
 def time_role(tr, batch, role, nrep):
@@ -277,8 +319,9 @@ def secondary_leg(device, steps=4, warmup=2):
         tr.train_step(*batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    regimes = regime_legs(tr, batch, B, steps, 1, torch.cuda.synchronize)
     roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=4)
-    return {"what": "forward K-hop propagation at N=1843 (BASELINE configs[3] shape, per-GPU batch 32), the kernel north_star "
+    return {**regimes, "what": "forward K-hop propagation at N=1843 (BASELINE configs[3] shape, per-GPU batch 32), the kernel north_star "
                     "sets the >= 40 % bf16-MFMA target on; measured in this same process after the headline run",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} mem={cfg['M']}x{cfg['D']} "
                                    f"cheb_k=3, batch {B}, full train step"},
@@ -299,6 +342,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the N=1843 propagation leg of the default run")
+    ap.add_argument("--batches-seen", type=int, default=0,
+                    help="curriculum position of the first timed step (model/MegaCRN.py:146-147): 0 = every step teacher-forced "
+                         "(the start of training); the line also carries value_no_teacher (no step teacher-forced) either way")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the no-teacher and evaluation-forward legs")
     ap.add_argument("--roles", default="1,2,3,4,5,6,7", help="GEMM roles timed for gemm_roles (diagnostics); 7 = the hoisted once-per-stack\n                    input-channel products of the bf16 mode (absent in the other modes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -344,6 +391,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tr.batches_seen = args.batches_seen
     loss = torch.zeros((), device=device)
     for _ in range(args.warmup):
         loss = tr.train_step(x, ycov, y)
@@ -359,6 +407,9 @@ def main():
         dt = float(tt.item())
     final_loss = float(loss.item())
     launches = lib.mcrn_last_launch_count()
+    regimes = None
+    if not args.no_regimes:
+        regimes = regime_legs(tr, batch, B * world, max(4, min(args.steps, 20)), 2, sync_all)
 
     # ---- roofline leg: HIP events around every launch of one GEMM role during real train steps
     roles, roof = {}, None
@@ -395,20 +446,25 @@ def main():
         # (oracle/megacrn_torch_cpu.py) at min(cores, 32) threads and at ONE thread (what the reference trainer pins,
         # model/traintest_MegaCRN.py:255-261): the full batch when a step fits ~1e12 algorithmic flops per leg, else as many
         # samples / sequence steps as fit (scaled linearly).  Second figure: the numpy port (the parity oracle) on one thread.
-        nthr = min(32, os.cpu_count() or 1)
+        # (the best of 8 / 16 / 32 threads: the op sizes of the small graphs do not scale to 32)
         sB, sT = cpu_sample(cfg, B, 1.4e12)
-        v, secs = cpu_baseline_torch(cfg, sB, sT, nthr)
+        sweep = {}
+        for cand in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32)}):
+            sweep[cand] = cpu_baseline_torch(cfg, sB, sT, cand)
+        nthr = max(sweep, key=lambda c: sweep[c][0])
+        v, secs = sweep[nthr]
         s1, t1 = cpu_sample(cfg, B, 0.7e12)
         v1, secs1 = cpu_baseline_torch(cfg, s1, t1, 1)
         sn, tn = cpu_sample(cfg, B, 0.25e12)
         vn, secsn = cpu_baseline_numpy(cfg, sn, tn, 1)
         cpu = {"value": round(v, 4), "unit": "samples/s", "cores": nthr, "kind": "port",
                "value_1thread": round(v1, 4), "value_numpy_port_1thread": round(vn, 4),
+               "thread_sweep": {str(c): round(sweep[c][0], 4) for c in sorted(sweep)},
                "cpu_model": cpu_model_string(), "host_cores": os.cpu_count(),
                "sample": f"oracle/megacrn_torch_cpu.py (the reference's ATen op sequence on PyTorch-CPU, autograd backward, "
                          f"clip_grad_norm_, torch Adam), warm (one untimed step on 2 samples first), one full train step of the "
                          f"same {cfg['label']} workload: {sB} of the {B} samples x {sT} of {cfg['T']} sequence steps on {nthr} "
-                         f"threads ({secs:.1f} s); value_1thread: {s1} samples x {t1} steps on 1 thread ({secs1:.1f} s); "
+                         f"threads (the best of {sorted(sweep)}: thread_sweep; {secs:.1f} s); value_1thread: {s1} samples x {t1} steps on 1 thread ({secs1:.1f} s); "
                          f"value_numpy_port_1thread: oracle/megacrn_oracle.py, {sn} samples x {tn} steps ({secsn:.1f} s); "
                          f"all scaled linearly to the full sequence length"}
 
@@ -428,7 +484,12 @@ def main():
                        "global_batch": gb, "parallelism": f"dp{world}"},
             "step_alg_tflops": round(step_flops * world / (dt / args.steps) / 1e12, 2),
             "kernel_launches_per_step": launches, "final_loss": round(final_loss, 5),
+            "teacher_regime": f"timed steps start at batches_seen = {args.batches_seen}: teacher-forcing probability "
+                              f"{2000.0 / (2000.0 + float(np.exp(min(args.batches_seen, 10 ** 6) / 2000.0))):.3f} "
+                              f"(cl_decay_steps 2000, model/MegaCRN.py:146-147); value_no_teacher = no step teacher-forced",
         }
+        if regimes:
+            out.update(regimes)
         if roof:
             out["roofline"] = roof
             out["gemm_roles"] = roles

@@ -295,6 +295,8 @@ struct Shp {   // one AGCN / cell geometry
     long long PSbh;               // Kp * ldh: one packed bf16 [Kp][B*H] matrix
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
+    bool mform;                   // bf16x3, N <= 352, fused model path: matrix-form Chebyshev terms (prop_mform.h): planes 1 .. nb are
+                                  // single-hop products [S1; 2 S1 S1 - I; S2; 2 S2 S2 - I] x plane 0, the d-grad weights are not folded
 };
 static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     Shp s;
@@ -313,6 +315,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.ldh = (long long)B * H;
     s.PSbh = (long long)s.Kp * s.ldh;
     s.fused = false;              // (set by plan_model: needs both output widths of the cell and the session precision)
+    s.mform = false;              // (set by plan_model)
     static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
     s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
@@ -337,6 +340,12 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     const uint16_t* STstk = nullptr;
     int Kp = 0, nb = 0;
     float *mu = nullptr, *mu_part = nullptr;    // column sums of a plane over its nodes (+ partials)
+    // matrix form of the small graphs (prop_mform.h): fragment images of [S1, 2 S1 S1, S2, 2 S2 S2] and of their transposes;
+    // dS then holds nbm output blocks per slab ([nslab][nbm][N*ldS], slab = nbm*N*ldS)
+    bool mform = false;
+    int nbm = 0;
+    const uint4* Mf[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint4* Mtf[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 static int nslab_S(int N) {
     // N <= 256: one ds_small workgroup per slab; its slab read + write is ~9 us whatever its K range, so fewer,
@@ -584,6 +593,13 @@ static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, in
 // second half lands in the extra plane dT that the element-wise consumers of dP[0] add (same mechanism as the fused
 // S^T chain of the small-graph path), so no reduction pass and still one writer per element.
 static const int PROPT_MAX_X = 3;                       // extra partial planes behind dT (K splits 1 .. 3)
+// K splits the launcher REALLY makes (bf16_split_plan) for a request `want` over nseg segments of seg_len, at a K tile of 64
+// and of 32: the consumers of the partial planes must know the count whatever tile the tuner picks, so a request is only
+// usable when both depths round it the same way and to itself (-1 otherwise).  want = 2 is exact for every K >= 2 tiles.
+static int bf16_eff_splits(int nseg, int seg_len, int want) {
+    auto eff = [&](int bk) { const int kt = nseg * cdiv(seg_len, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    return eff(64) == eff(32) && eff(64) == want ? want : -1;
+}
 struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
 static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
 // hoisted (the packed operand dPb = [nb][Kp][B*H]): only the state channels of plane 0 receive a propagated gradient here;
@@ -605,13 +621,16 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
         // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
         p.slab = dT - dP; p.slab2 = s.PS; p.cin_first_only = 1;
         const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N};
-        nsplit = split_env >= 2 && split_env <= 1 + PROPT_MAX_X ? split_env : 2;
+        // (a request the launcher would round to fewer splits - short K: N <= 64 at cheb_k = 3 - is not taken: the consumers
+        //  would add partial planes that nothing wrote; 2 is exact for any K of two tiles or more)
+        nsplit = split_env >= 2 && split_env <= 1 + PROPT_MAX_X && bf16_eff_splits(u.nb, s.N, split_env) == split_env ? split_env : 2;
         if (split_env == 0) {
             auto it = g_tuned_split.find(key);
-            if (it != g_tuned_split.end()) nsplit = it->second;
+            if (it != g_tuned_split.end() && bf16_eff_splits(u.nb, s.N, it->second) == it->second) nsplit = it->second;
             else if (g_tuning) {
                 float best = 1e30f;
                 for (int ns = 2; ns <= 1 + PROPT_MAX_X; ++ns) {
+                    if (bf16_eff_splits(u.nb, s.N, ns) != ns) continue;
                     CKI(bf16_gemm(p, true, ns, ROLE_PROPT, alg, st));        // tunes the tile for this split count
                     if (g_last_tune_ms < best) { best = g_last_tune_ms; nsplit = ns; }
                 }
@@ -619,7 +638,9 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
                 if (getenv("MCRN_TUNE_LOG")) fprintf(stderr, "[mcrn tune] role 4 M=%d N=%d: %d K splits\n", p.M, p.N, nsplit);
             }
         }
+        if (bf16_eff_splits(u.nb, s.N, nsplit) != nsplit) nsplit = 1;          // (a single K tile: nothing to split)
         *used_dT = nsplit - 1;
+        if (nsplit == 1) { p.slab = 0; p.slab2 = 0; p.cin_first_only = 0; }
     }
     return bf16_gemm(p, true, nsplit, ROLE_PROPT, alg, st);
 }
@@ -687,10 +708,67 @@ static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long l
     return 0;
 }
 
+// ---- matrix-form single-hop propagation of the small graphs (prop_mform.h) -------------------------------------------
+struct Prop1Cfg { int ct, stream, cap, bwd_ny; };
+static const Prop1Cfg& prop1_cfg() {
+    static const Prop1Cfg c = {
+        getenv("MCRN_PROP1_CT") ? atoi(getenv("MCRN_PROP1_CT")) : 2,
+        getenv("MCRN_PROP1_STREAM") ? atoi(getenv("MCRN_PROP1_STREAM")) : 1,
+        getenv("MCRN_PROP1_CAP") ? atoi(getenv("MCRN_PROP1_CAP")) : 0,
+        getenv("MCRN_PROP1_BWD_NY") ? atoi(getenv("MCRN_PROP1_BWD_NY")) : 0 /* 0: one group per block */};
+    return c;
+}
+static int prop1_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
+    if (!aligned16(Z)) FAIL("matrix-form propagation: plane set not 16-byte aligned");
+    Prop1P q;
+    memset(&q, 0, sizeof q);
+    const int nb = u.nbm;
+    for (int k = 0; k < nb; ++k) {
+        q.Sf[k] = u.Mf[k]; q.src[k] = Z; q.out[k] = Z + (long long)(1 + k) * s.PS;
+        if (s.K == 3 && (k & 1)) { q.add0[k] = Z; q.coef0[k] = -1.f; }          // T2 x = (2 S S) x - x
+    }
+    q.ny = nb; q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld;
+    const Prop1Cfg& c = prop1_cfg();
+    const double alg = nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, ex = nb * 2.0 * (double)s.N * s.N * (double)s.ld;
+    MCRN_PROF_WRAP(ROLE_PROP, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
+    return 0;
+}
+// backward: dP[0] += sum_k A_k^T dP[1 + k] (- dP[2] - dP[4]: the "- I" of the T2 blocks); the nb blocks are dealt to ny groups,
+// group 0 accumulates into plane 0, group y > 0 stores its partial into the extra plane dT + (y - 1) * PS that the
+// element-wise consumers of plane 0 add (one writer per element, fixed order)
+static int prop1_bwd(const Shp& s, const Sup& u, float* dP, float* dT, int* used_dT, hipStream_t st) {
+    if (!aligned16(dP) || !dT) FAIL("matrix-form propagation: gradient planes not aligned / no partial planes");
+    Prop1P q;
+    memset(&q, 0, sizeof q);
+    const int nb = u.nbm;
+    const Prop1Cfg& c = prop1_cfg();
+    int ny = c.bwd_ny > 0 ? c.bwd_ny : nb;
+    if (ny > nb || nb % ny || nb / ny > 2 || ny - 1 > PROPT_MAX_X) ny = nb;
+    const int nseg = nb / ny;
+    for (int k = 0; k < nb; ++k) { q.Sf[k] = u.Mtf[k]; q.src[k] = dP + (long long)(1 + k) * s.PS; }
+    for (int y = 0; y < ny; ++y) {
+        q.out[y] = y == 0 ? dP : dT + (long long)(y - 1) * s.PS;
+        int na = 0;
+        auto push = [&](const float* a, float cf) { if (na == 0) { q.add0[y] = a; q.coef0[y] = cf; } else { q.add1[y] = a; q.coef1[y] = cf; } ++na; };
+        if (y == 0) push(dP, 1.f);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int k = y * nseg + sg;
+            if (s.K == 3 && (k & 1)) push(dP + (long long)(1 + k) * s.PS, -1.f);
+        }
+        if (na > 2) FAIL("matrix-form propagation: more than two addends in one group");
+    }
+    q.ny = ny; q.nseg = nseg; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld;
+    if (used_dT) *used_dT = ny - 1;
+    const double alg = nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, ex = nb * 2.0 * (double)s.N * s.N * (double)s.ld;
+    MCRN_PROF_WRAP(ROLE_PROPT, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
+    return 0;
+}
+
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr,
                     uint16_t* Pb = nullptr, bool packed = false) {
     if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st, Pb, packed);
+    if (s.mform) return prop1_fwd(s, u, Z, st);
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
@@ -850,8 +928,11 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
-    const bool fused_bwd = use_prop2(u, s) && aligned16(dP) && dT != nullptr;
-    if (fused_bwd) {
+    const bool fused_bwd = !s.mform && use_prop2(u, s) && aligned16(dP) && dT != nullptr;
+    if (s.mform) {
+        // matrix form: the whole transposed propagation is ONE single-hop launch over the nb blocks (prop_mform.h)
+        CKI(prop1_bwd(s, u, dP, dT, used_dT, st));
+    } else if (fused_bwd) {
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
@@ -859,7 +940,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         if (used_dT) *used_dT = 1;
         const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
-    } else if (s.K == 3 && small) {
+    } else if (s.K == 3 && small) {   // (not reached in the matrix form: its branch is the first of this chain)
         PropP q;
         memset(&q, 0, sizeof q);
         q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
@@ -884,7 +965,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
-    const bool ds_small_path = !u.defer && small && aligned16(X) && ds_small_enabled();
+    const bool ds_small_path = !u.defer && (s.mform ? s.N <= 256 : small) && aligned16(X) && ds_small_enabled();
     if (cell_ds && cell_ds->nseg > 0 && !ds_small_path)
         // the update call of this cell queued its d1t x0^T / e2 x1^T segments for a merged launch; the gate call must
         // take the same branch, or those contributions to dS would be silently dropped
@@ -898,8 +979,16 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         DsP q_local;
         DsP& q = cell_ds ? *cell_ds : q_local;
         if (!cell_ds || cell_ds->nseg == 0) memset(&q, 0, sizeof q);
-        const int s0 = q.nseg, own = s.K == 3 ? 2 : 1;
+        const int s0 = q.nseg, own = s.mform ? 1 : (s.K == 3 ? 2 : 1);
+        const int nblk = s.mform ? u.nbm : 2;
         q.nseg = s0 + own; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.ldc = u.ldS; q.slab = u.slab;
+        if (s.mform) {
+            // matrix form: dA_k = dP_k x0^T - plane 0 is the only right operand, one segment per call and block
+            for (int k = 0; k < nblk; ++k) {
+                q.A[k][s0] = dP + (long long)(1 + k) * s.PS; q.B[k][s0] = X;
+                q.C[k] = u.dS + (long long)k * s.N * u.ldS;
+            }
+        } else
         for (int b = 0; b < 2; ++b) {
             const long long g1 = 1 + b * (s.K - 1);
             q.A[b][s0] = dP + g1 * s.PS;       q.B[b][s0] = X;                      // d1t x0^T
@@ -907,7 +996,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             q.C[b] = u.dS + (long long)b * u.sup_stride;
         }
         if (!cell_ds || cell_ds_last) {
-            const double ex = 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
+            const double ex = nblk * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
             hipStream_t ds_st = st;
             if (side) {
                 CK(hipEventRecord(g_side.ready[buf], st));
@@ -918,7 +1007,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                 hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
                 static const bool dbg_skip = getenv("MCRN_DBG_SKIP_DS") != nullptr;   // timing experiments only (wrong gradients)
                 if (!dbg_skip)
-                MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st), ex, 2.0 * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
+                MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st, nblk), ex, nblk * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
             }
             if (side) {
                 const int nb_ = cell_ds ? 2 : 1;          // a merged launch reads the plane sets of both calls
@@ -930,6 +1019,34 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                 }
                 g_side.any = true;
             }
+        }
+    } else if (s.mform) {
+        // matrix form on the tiled GEMM (256 < N <= 352): dA_k += dP_k x0^T, two blocks per launch, split-K into slabs
+        hipStream_t ds_st = st;
+        if (side) {
+            CK(hipEventRecord(g_side.ready[buf], st));
+            CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
+            ds_st = g_side.st;
+        }
+        for (int k0 = 0; k0 < u.nbm; k0 += 2) {
+            GemmP p = gp();
+            p.M = s.N; p.N = s.N; p.K = (int)s.ld;
+            p.am = plain(s.ld); p.ak = plain(1);
+            p.bn = plain(s.ld); p.bk = plain(1);
+            p.cm = plain(u.ldS); p.cn = plain(1);
+            p.nbatch = 2; p.beta = 1.f; p.slab = u.slab;
+            for (int b = 0; b < 2; ++b) {
+                p.A[b] = dP + (long long)(1 + k0 + b) * s.PS;
+                p.B[b] = X;
+                p.C[b] = u.dS + (long long)(k0 + b) * s.N * u.ldS;
+                p.Cin[b] = p.C[b];
+            }
+            p.alg_flops = 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
+            CKI(gemm(p, true, true, u.nslab, ROLE_DS, ds_st));
+        }
+        if (side) {
+            CK(hipEventRecord(g_side.done[buf], g_side.st));
+            g_side.pending[buf] = true; g_side.paired[buf] = false; g_side.any = true;
         }
     } else
     {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
@@ -957,7 +1074,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
         }
     }
-    if (fused_bwd) {
+    if (fused_bwd || s.mform) {
         // done above
     } else if (small) {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b : two K-segments into one accumulator
         PropP q;
@@ -1203,8 +1320,9 @@ static int relu_softmax_rows_bwd(const float* L, long long ldl, const float* G, 
     return 0;
 }
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
-struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
-static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n;
+                 float* M2[2]; uint4* mfrag[8]; /* matrix form: 2 S S per support, images of [S1, M2_1, S2, M2_2] (cheb_k = 2: [S1, S2]) + transposes */ };
+static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o, int mform_K = 0) {
     size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
     o.ldS = ldS;
     o.E1 = b.take<float>(nd); o.E2 = b.take<float>(nd);
@@ -1217,6 +1335,8 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     for (int i = 0; i < 4; ++i) o.frag[i] = N <= PROP2_MAX_N ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     o.simg_n = (N + 3) & ~3;
     for (int i = 0; i < 4; ++i) o.simg[i] = N > 256 ? b.take<uint4>(bimg_uint4(N, N)) : nullptr;
+    for (int i = 0; i < 2; ++i) o.M2[i] = mform_K == 3 ? b.take<float>(nn) : nullptr;
+    for (int i = 0; i < 8; ++i) o.mfrag[i] = mform_K ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
 }
 static int transpose(float* dst, long long ldd, const float* src, long long lds_, const float* add,
                      long long lda, int N, hipStream_t st) {
@@ -1240,7 +1360,7 @@ struct ExactFp32 {
     ~ExactFp32() { g_precision = saved; }
 };
 static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
-                        const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st) {
+                        const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st, int mform_K = 0) {
     // The logits go through relu: a logit within the bf16x3 error (1e-5) of zero would get the wrong SIGN and flip
     // its mask in the backward pass (one whole row of dWe1 / dWe2 off by 1e-2: tests/test_gpu_parity.py, H = 8,
     // mem_num = 4).  These three GEMMs are tiny and run once per step, so they are evaluated in exact fp32, like
@@ -1270,8 +1390,33 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
     if (want_T) {
         CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
         CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
+        if (mform_K) {
+            // matrix form (prop_mform.h): M2_s = 2 S_s S_s once per step in exact fp32 (model/MegaCRN.py:20-22 builds the same
+            // matrix on every AGCN call), then the fragment images of every block and of its transpose in ONE launch
+            if (ldg != o.ldS) FAIL("matrix form: supports must share the workspace row stride");
+            const int nb = 2 * (mform_K - 1);
+            if (mform_K == 3) {
+                ExactFp32 exact_m2;
+                GemmP p = gp();
+                p.M = N; p.N = N; p.K = N; p.nbatch = 2; p.alpha = 2.f;
+                p.am = plain(ldg); p.ak = plain(1);
+                p.bk = plain(ldg); p.bn = plain(1);
+                p.cm = plain(o.ldS); p.cn = plain(1);
+                for (int b = 0; b < 2; ++b) { p.A[b] = b ? g2 : g1; p.B[b] = b ? g2 : g1; p.C[b] = o.M2[b]; p.Cin[b] = nullptr; }
+                CKI(gemm(p, true, false, 0, ROLE_MISC, st));
+            }
+            const float* src[8]; int tr[8];
+            for (int k = 0; k < nb; ++k) {
+                const int sidx = k / (mform_K - 1), t2 = mform_K == 3 && (k & 1);
+                src[k] = t2 ? o.M2[sidx] : (sidx ? g2 : g1); tr[k] = 0;
+                src[nb + k] = src[k]; tr[nb + k] = 1;
+            }
+            uint4* dst[8];
+            for (int k = 0; k < nb; ++k) { dst[k] = o.mfrag[k]; dst[nb + k] = o.mfrag[4 + k]; }
+            ++g_launches; CK(launch_sfrag_multi(src, tr, dst, 2 * nb, ldg, N, st));
+        } else
         CKI(build_frags(g1, g2, ldg, N, o.frag, st));
-        if (o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
+        if (!mform_K && o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
             const float* src[4] = {g1, g2, o.St1, o.St2};
             const long long lds_[4] = {ldg, ldg, o.ldS, o.ldS};
             for (int i = 0; i < 4; ++i) { ++g_launches; CK(launch_bimg_build(src[i], 1LL, lds_[i], N, N, o.simg_n, 1, o.simg[i], st)); }
@@ -1348,7 +1493,7 @@ static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long l
 static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st, uint4* imgf = nullptr,
                  uint4* imgd = nullptr) {
     long long tot = (long long)s.G * s.Cp * O;
-    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, (g_prop_bf16 || s.K != 3) ? 0 : 1);
+    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, (g_prop_bf16 || s.mform || s.K != 3) ? 0 : 1);
     if (imgf && g_precision == MCRN_BF16X3) {
         const int Kp = s.G * s.Cp;
         {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
@@ -1395,6 +1540,8 @@ struct ModelPlan {
     float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
     float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
     bool defer_ds;
+    bool mform;                       // matrix-form Chebyshev terms on the small graphs (prop_mform.h)
+    float* dAm;                       // ... the reduced adjacency-gradient blocks [nb][N*ldS]
     float *dU_e, *dG_e, *dU_d, *dG_d;
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
@@ -1438,15 +1585,26 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.sd = mk_shape(B, N, od + yd, Hd, K, P.bf16);
     P.ldS = d->precision == MCRN_BF16 ? (N + 7) & ~7 : (N + 3) & ~3;
     P.nslabS = nslab_S(N);
-    plan_sup(b, N, M, D, P.ldS, P.sup);
     P.defer_ds = false; P.ndef_d = P.ndef_e = 0;
     {
         // experimental (measured slower at METR-LA: the long deferred launch starves the critical path): opt-in
         static const bool defer_env = getenv("MCRN_DEFER_DS") && atoi(getenv("MCRN_DEFER_DS")) == 1;
-        P.defer_ds = defer_env && N <= 256 && d->precision == MCRN_BF16X3 && (P.sd.ld % 4) == 0;
+        P.defer_ds = defer_env && K <= 3 && N <= 256 && d->precision == MCRN_BF16X3 && (P.sd.ld % 4) == 0;
         if (P.defer_ds) P.ndef_d = ds_deferred_chunks((int)P.sd.ld);
     }
-    P.dS = b.take<float>((size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS);   // per support: [per-call split-K slabs | decoder deferred slabs]
+    {
+        // matrix-form Chebyshev terms (prop_mform.h), the default of the bf16x3 sessions on graphs of N <= 352: every AGCN
+        // call is one single-hop product over nb independent row blocks (MCRN_MFORM=0: the fused two-hop feature recursion)
+        static const bool mform_off = getenv("MCRN_MFORM") && atoi(getenv("MCRN_MFORM")) == 0;
+        static const bool fused_on = getenv("MCRN_AGCN_FUSED") && atoi(getenv("MCRN_AGCN_FUSED")) == 1;
+        P.mform = !mform_off && !fused_on && !P.defer_ds && d->precision == MCRN_BF16X3 && K <= 3 &&
+                  prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
+        P.se.mform = P.sd.mform = P.mform;
+    }
+    plan_sup(b, N, M, D, P.ldS, P.sup, P.mform ? K : 0);
+    const int nblkS = P.mform ? 2 * (K - 1) : 2;                           // output blocks of the adjacency gradient
+    P.dS = b.take<float>((size_t)nblkS * (P.nslabS + P.ndef_d) * N * P.ldS);   // per support: [per-call split-K slabs | decoder deferred slabs]
+    P.dAm = P.mform ? b.take<float>((size_t)nblkS * N * P.ldS) : nullptr;
     const Shp* sh[4] = {&P.se, &P.se, &P.sd, &P.sd};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) {
@@ -1592,6 +1750,12 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
     u.defer = false;
     u.Sstk = P.Sstk; u.STstk = P.STstk; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
+    if (P.mform) {
+        u.mform = true; u.nbm = P.nb;
+        for (int k = 0; k < P.nb; ++k) { u.Mf[k] = P.sup.mfrag[k]; u.Mtf[k] = P.sup.mfrag[4 + k]; }
+        u.slab = (long long)P.nb * N * P.ldS;          // one slab = the nb output blocks side by side
+        u.sup_stride = 0;
+    }
     return u;
 }
 
@@ -1813,7 +1977,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
             CKI(zero_cols(P.Ydec + sd.ZT, sd.ZT, sd.Cp, Hd, Hd + od, R, To - 1, ps));
         }
     }
-    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
+    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st, P.mform ? d->cheb_k : 0));
     Sup u = model_sup(P, N);
     if (P.bf16) CKI(build_stacks(P, u, N, d->cheb_k, st));
     // ---- encoder (MegaCRN.py:65-83): inputs for all t packed once
@@ -1901,7 +2065,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
     Sup u = model_sup(P, N);
-    CK(hipMemsetAsync(P.dS, 0, (size_t)2 * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
+    CK(hipMemsetAsync(P.dS, 0, (size_t)(P.mform ? P.nb : 2) * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_T * od * Hd * sizeof(float), st));
@@ -2093,6 +2257,30 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
                          P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
+    } else if (P.mform) {
+        // matrix form: fold the slabs of all nb blocks (fixed order), then the chain rule of M2 = 2 S S onto S in exact fp32
+        //   dS_s = dA[S_s] + 2 (dM2_s S_s^T + S_s^T dM2_s)        (the "- I" of T2 carries no gradient)
+        const long long nn = (long long)N * P.ldS;
+        LAUNCH(k_reduce_slabs, dim3(cdiv(P.nb * nn, 64)), dim3(1024), 0, st, P.dAm, (const float*)P.dS, P.nslabS, P.nb * nn, P.nb * nn, 0);
+        if (d->cheb_k == 3) {
+            ExactFp32 exact_chain;
+            for (int which = 0; which < 2; ++which) {
+                GemmP q = gp();
+                q.M = N; q.N = N; q.K = N; q.nbatch = 2; q.alpha = 2.f; q.beta = 1.f;
+                q.am = plain(P.ldS); q.ak = plain(1);
+                if (which == 0) { q.bk = plain(1); q.bn = plain(P.ldS); } else { q.bk = plain(P.ldS); q.bn = plain(1); }
+                q.cm = plain(P.ldS); q.cn = plain(1);
+                for (int b = 0; b < 2; ++b) {
+                    const float* dT = P.dAm + (long long)(2 * b + 1) * nn;
+                    q.A[b] = which == 0 ? dT : (b ? P.sup.St2 : P.sup.St1);            // dT S^T   |   S^T dT
+                    q.B[b] = which == 0 ? (b ? P.sup.g2 : P.sup.g1) : dT;
+                    q.C[b] = P.dAm + (long long)(2 * b) * nn; q.Cin[b] = q.C[b];
+                }
+                CKI(gemm(q, true, which == 0, 0, ROLE_MISC, st));
+            }
+        }
+        CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dAm,
+                         P.dAm + (long long)(d->cheb_k - 1) * nn, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
     } else
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
                      P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
@@ -2319,6 +2507,9 @@ int mcrn_autotune_import(const int* buf, long long n) {
             TuneKey k; memcpy(&k, buf + i + 2, sizeof k); a[k] = cfg;
         } else if (kind == 1) {
             if (cfg < 0 || cfg >= NCFG_BF16) FAIL("autotune_import: bf16 tile configuration %d out of range", cfg);
+            // stream-K tiles ignore the K split that the consumers of a split product count on (hoist_inputs, go_grad_bf16, the
+            // partial planes of the transposed propagation); the tuner never emits them, a peer's table must not either
+            if (bf16_cfg_is_sk(cfg)) FAIL("autotune_import: stream-K tile configuration %d is not importable", cfg);
             Bf16Key k; memcpy(&k, buf + i + 2, sizeof k); b[k] = cfg;
         } else {
             if (cfg < 1 || cfg > 1 + PROPT_MAX_X) FAIL("autotune_import: split count %d out of range", cfg);

@@ -98,10 +98,24 @@ struct Prop2P {
     int N, ncols;
 };
 
+// matrix-form single-hop propagation (prop_mform.h): group y (grid.y) multiplies the blocks y*nseg .. y*nseg + nseg - 1
+struct Prop1P {
+    const uint4* Sf[4];         // fragment image (k_sfrag_build layout) of block k: forward [S1, 2 S1 S1, S2, 2 S2 S2], backward their transposes
+    const float* src[4];        // right operand plane of block k (N x ncols, row stride ld)
+    float* out[4];              // output plane of group y
+    const float* add0[4];       // fp32 addends of group y (nullable) ...
+    const float* add1[4];
+    float coef0[4], coef1[4];   // ... and their factors (+1: the accumulating plane, -1: the "- I" of a T2 block)
+    int ny, nseg, N, ncols;
+    long long ld;
+};
+
 struct DsP {
-    const float* A[2][4];       // [support][segment]  (2 segments per AGCN call at cheb_k = 3; a cell's two calls share one launch)
-    const float* B[2][4];
-    float* C[2];                // slab 0 of the support; slab z at + z*slab
+    // [output block][segment].  Feature-recursion path: block = support, 2 segments per AGCN call at cheb_k = 3 (d1t x0^T, e2 x1^T).
+    // Matrix form (prop_mform.h): block = Chebyshev block k < nb, ONE segment per call (dP_k x0^T).  A cell's two calls share one launch.
+    const float* A[4][4];
+    const float* B[4][4];
+    float* C[4];                // slab 0 of the block; slab z at + z*slab
     long long slab;
     int nseg, N, ncols, kchunk; // kchunk multiple of 16
     long long ld, ldc;
@@ -182,7 +196,10 @@ hipError_t launch_bimg_build(const float* src, long long sk, long long sn, int K
 hipError_t launch_prop_small(const PropP& p, int nbatch, hipStream_t st);
 hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st);
 hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st);
-hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st);
+hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int nblk = 2);
+hipError_t launch_prop1(const Prop1P& p, int ct, bool stream, int cap, hipStream_t st);
+// fragment images of n <= 8 matrices (S or S^T each) in one launch
+hipError_t launch_sfrag_multi(const float* const* S, const int* transpose, uint4* const* out, int n, long long ldS, int N, hipStream_t st);
 hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st);
 hipError_t launch_sfrag(const float* S, long long ldS, int N, int transpose, uint4* out, hipStream_t st);
 bool agcn_fused_ok(int N, int H, int d, int O, long long ld, int Cp);

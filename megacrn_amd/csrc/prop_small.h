@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * NF) void prop_small_kernel(const PropP p) {
 // straight into the next B image (each lane owns 4 consecutive rows = one 8-byte half of a B-fragment
 // vector) and S stays in registers for both hops.
 // ---------------------------------------------------------------------------------------------
-template <int NF, int CT>      // CT = 32-column tiles per workgroup unit (1, 2 or 3)
+template <int NF, int CT, bool STREAM = (NF > 8)>      // CT = 32-column tiles per workgroup unit (1 .. 4)
 struct PropBlock {
     static constexpr int KS = 2 * NF;
     static constexpr int IMG = CT * KS * 2 * 64;     // uint4
@@ -142,7 +142,8 @@ struct PropBlock {
     // has 11 waves (3 per SIMD: 168 VGPRs each) - S is not register-stationary there: every k-step's hi and lo fragments
     // are streamed from L2 (coalesced 2 KB per wave and k-step; the 0.5 MB image is shared by every workgroup) through a
     // small register ring, a few k-steps ahead of the MFMAs that use them.
-    static constexpr bool WIDE = NF > 8;
+    // (STREAM may also be asked for at NF <= 8 - prop_mform.h: ~110 instead of ~220 VGPRs, two workgroups per CU)
+    static constexpr bool WIDE = STREAM;
     static constexpr int NAL = WIDE ? 1 : KS;        // fragments held in registers (hi and lo alike)
     static constexpr int RD = 3;                     // ring depth of the streamed fragments
     static_assert(!(WIDE && CT == 1), "the wide variant is built for 2 / 3 column tiles");
@@ -216,8 +217,17 @@ struct PropBlock {
             unsigned voff = 0;
             auto kof = [&](int i) { int k = i + ks0; return k >= KS ? k - KS : k; };
             auto issue = [&](int slot, int i) {
-                const unsigned char* b = sbase + (long long)kof(i) * 2048;       // k-step image: [hi | lo] x 64 lanes x 16 B
-                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                const unsigned char* b0 = sbase + (long long)kof(i) * 2048;      // k-step image: [hi | lo] x 64 lanes x 16 B
+                // ("s" operands need readfirstlane even when uniform by construction; folded away where the compiler knows it)
+                const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)b0);
+                const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b0 >> 32));
+                const unsigned char* b = reinterpret_cast<const unsigned char*>(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
+                // s_nop 4: the compiler may produce `b` with VALU instructions (v_readfirstlane / v_readlane of a spilled offset, a
+                // 64-bit VALU add when it runs out of SGPRs) right in front of this block.  A VMEM instruction that reads an SGPR
+                // written by a VALU instruction needs 5 wait states, and the hazard recogniser cannot see into inline asm: without
+                // them the load uses the STALE register pair - one k-step of wrong fragments (found with tools/kbench/prop1_test:
+                // 3e-2 .. 6e-2 errors in exactly the variants whose ISA had such a pair; tools/isa_hazards.py scans for it).
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
                              : "=&v"(rh[slot]), "=&v"(rl[slot]) : "v"(voff), "s"(b));
             };
             if constexpr (WIDE) {
@@ -760,13 +770,13 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
 #endif
 #undef MCRN_TLA
 }
-static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st) {
+static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int nblk = 2) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     int kc = ((p.ncols + nslab - 1) / nslab + 31) / 32 * 32;
     if (kc < 64) kc = 64;
     p.kchunk = kc;
-    dim3 grid((p.ncols + kc - 1) / kc, 2);
+    dim3 grid((p.ncols + kc - 1) / kc, nblk);
     switch (NF) {
         case 1: hipLaunchKernelGGL(ds_small_kernel<1>, grid, dim3(64), 0, st, p); break;
         case 2: hipLaunchKernelGGL(ds_small_kernel<2>, grid, dim3(128), 0, st, p); break;

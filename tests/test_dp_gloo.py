@@ -214,7 +214,8 @@ def test_ranks_adopt_rank0_tile_table_world2():
 
 def test_autotune_import_rejects_malformed_tables():
     from megacrn_amd import _lib
-    for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 6] + [0] * 6 + [-1]):
+    # (last: a stream-K bf16 tile, configurations 10..12 - it would ignore the K split its consumers count on)
+    for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 6] + [0] * 6 + [-1], [1, 6, 1, 7372, 1152, 1843, 1, 1, 11]):
         with pytest.raises(RuntimeError):
             _lib.autotune_import(bad)
     _lib.autotune_import([])

@@ -215,6 +215,29 @@ def test_shipped_kernels_use_no_packed_fp32_valu():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_shipped_kernels_have_no_valu_sgpr_to_vmem_hazard():
+    """Build guard for the inline-asm loads (prop_small.h's streamed adjacency fragments, the LDS-DMA issue blocks): a VMEM
+    instruction that reads an SGPR pair written by a VALU instruction (v_readfirstlane / v_readlane ...) needs 5 wait states,
+    and the compiler's hazard recogniser cannot see into asm text.  Round 4 found the forward propagation of 256 < N <= 352
+    and several new variants one k-step wrong from exactly this (tools/isa_hazards.py; tools/kbench/prop1_test)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "megacrn_amd", "libmegacrn_hip.so")
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(root, "tools", "isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(so) and os.path.exists(mod.OBJCOPY) and os.path.exists(mod.OBJDUMP)):
+        pytest.skip("library or LLVM binutils not present")
+    # the scanner itself: a planted hazard is found, the same sequence behind s_nop 4 is not
+    planted = ("0000 <k>:\n\tv_readfirstlane_b32 s2, v66    // 0\n\tv_readfirstlane_b32 s3, v67    // 4\n"
+               "\tglobal_load_dwordx4 v[66:69], v126, s[2:3]    // 8\n")
+    assert len(mod.scan_disassembly(planted)) == 1
+    assert not mod.scan_disassembly(planted.replace("\tglobal_load", "\ts_nop 4    // 6\n\tglobal_load"))
+    hits, nloads = mod.scan_library(so)
+    assert nloads > 1000                      # we really looked at the kernels
+    assert not hits, f"{len(hits)} VALU-SGPR -> VMEM hazards, first: {hits[0]}"
+
+
 def _device_code_objects(tmp):
     """(path, disassembler) of every gfx950 code object inside the shipped library, or None when tools are absent."""
     import re

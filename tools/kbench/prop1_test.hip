@@ -1,0 +1,196 @@
+// Stand-alone correctness + timing harness for megacrn_amd/csrc/prop_mform.h (matrix-form single-hop propagation) against
+// the fused two-hop kernels of prop_small.h (no torch).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-vectorize -o prop1_test prop1_test.hip
+//   ./prop1_test N ncols [reps]
+// Prints, per variant (ct, stream, groups x blocks-per-group, cap): max relative error vs a float64 CPU product of the same
+// inputs (forward and backward) and the average launch time over `reps` launches that rotate through NSET plane sets
+// (operands come from the memory side, as in a train step).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <random>
+#define MCRN_PROBE 1
+#include "../../megacrn_amd/csrc/prop_mform.h"
+using namespace mcrn;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 3) { printf("usage: prop1_test N ncols [reps]\n"); return 1; }
+    const int N = atoi(argv[1]), ncols = atoi(argv[2]), reps = argc > 3 ? atoi(argv[3]) : 40;
+    const int NSET = 6, nb = 4;
+    const long long ld = ncols, PS = (long long)N * ld, ZT = 5 * PS;
+    const int NF = (N + 31) / 32;
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    // blocks: row-stochastic S1, S2 and M2_s = 2 S_s S_s (float64 product rounded to fp32)
+    std::vector<float> hA((size_t)nb * N * N);
+    for (int s = 0; s < 2; ++s) {
+        float* S = hA.data() + (size_t)(2 * s) * N * N;
+        for (int i = 0; i < N; ++i) {
+            double sum = 0;
+            for (int j = 0; j < N; ++j) { S[(size_t)i * N + j] = expf(2.f * U(rng)); sum += S[(size_t)i * N + j]; }
+            for (int j = 0; j < N; ++j) S[(size_t)i * N + j] = (float)(S[(size_t)i * N + j] / sum);
+        }
+        float* M2 = hA.data() + (size_t)(2 * s + 1) * N * N;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                double a = 0;
+                for (int k = 0; k < N; ++k) a += (double)S[(size_t)i * N + k] * S[(size_t)k * N + j];
+                M2[(size_t)i * N + j] = (float)(2.0 * a);
+            }
+    }
+    std::vector<float> hZ((size_t)NSET * ZT);
+    for (auto& v : hZ) v = U(rng);
+    float *dA, *dZ, *dZ0, *dX;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dZ, hZ.size() * 4)); CK(hipMalloc(&dZ0, hZ.size() * 4)); CK(hipMalloc(&dX, (size_t)3 * PS * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dZ0, hZ.data(), hZ.size() * 4, hipMemcpyHostToDevice));
+    uint4* frag[8];
+    {
+        const float* S[8]; int tr[8];
+        for (int i = 0; i < 8; ++i) { CK(hipMalloc(&frag[i], sfrag_uint4(N) * 16)); S[i] = dA + (size_t)(i & 3) * N * N; tr[i] = i >> 2; }
+        SfragMultiP q;
+        for (int i = 0; i < 8; ++i) { q.S[i] = S[i]; q.out[i] = frag[i]; q.transpose[i] = tr[i]; }
+        q.ldS = N; q.N = N; q.NF = NF; q.n = 8;
+        CK(launch_sfrag_multi(q, 0));
+    }
+    // old-path fragments: S1, S2, S1^T, S2^T = blocks 0, 2, 4, 6
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto reset = [&]() { return hipMemcpy(dZ, dZ0, hZ.size() * 4, hipMemcpyDeviceToDevice); };
+
+    // ---- CPU references on a sample of columns (float64)
+    const int ncheck = 96;
+    std::vector<int> cols(ncheck);
+    for (int i = 0; i < ncheck; ++i) cols[i] = (int)(((long long)i * 9973 + 17) % ncols);
+    cols[0] = 0; cols[1] = ncols - 1;
+    const float* Z0 = hZ.data();    // set 0
+    std::vector<double> refF((size_t)nb * N * ncheck), refB((size_t)N * ncheck);
+    for (int k = 0; k < nb; ++k)
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < ncheck; ++c) {
+                double a = 0;
+                for (int j = 0; j < N; ++j) a += (double)hA[((size_t)k * N + i) * N + j] * Z0[(size_t)j * ld + cols[c]];
+                if (k & 1) a -= Z0[(size_t)i * ld + cols[c]];
+                refF[((size_t)k * N + i) * ncheck + c] = a;
+            }
+    for (int i = 0; i < N; ++i)
+        for (int c = 0; c < ncheck; ++c) {
+            double a = Z0[(size_t)i * ld + cols[c]];
+            for (int k = 0; k < nb; ++k) {
+                const float* P = Z0 + (size_t)(1 + k) * PS;
+                for (int j = 0; j < N; ++j) a += (double)hA[((size_t)k * N + j) * N + i] * P[(size_t)j * ld + cols[c]];
+                if (k & 1) a -= P[(size_t)i * ld + cols[c]];
+            }
+            refB[(size_t)i * ncheck + c] = a;
+        }
+    std::vector<float> got((size_t)ZT), gx((size_t)3 * PS);
+    auto check_fwd = [&]() -> double {
+        double e = 0, m = 0;
+        for (int k = 0; k < nb; ++k)
+            for (int i = 0; i < N; ++i)
+                for (int c = 0; c < ncheck; ++c) {
+                    const double r = refF[((size_t)k * N + i) * ncheck + c], g = got[(size_t)(1 + k) * PS + (size_t)i * ld + cols[c]];
+                    e = fmax(e, fabs(r - g)); m = fmax(m, fabs(r));
+                }
+        return e / m;
+    };
+    auto check_bwd = [&](int nx) -> double {
+        double e = 0, m = 0;
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < ncheck; ++c) {
+                const double r = refB[(size_t)i * ncheck + c];
+                double g = got[(size_t)i * ld + cols[c]];
+                for (int x = 0; x < nx; ++x) g += gx[(size_t)x * PS + (size_t)i * ld + cols[c]];
+                e = fmax(e, fabs(r - g)); m = fmax(m, fabs(r));
+            }
+        return e / m;
+    };
+    auto fwd_params = [&](float* Z) {
+        Prop1P p; memset(&p, 0, sizeof p);
+        for (int k = 0; k < nb; ++k) {
+            p.Sf[k] = frag[k]; p.src[k] = Z; p.out[k] = Z + (size_t)(1 + k) * PS;
+            if (k & 1) { p.add0[k] = Z; p.coef0[k] = -1.f; }
+        }
+        p.ny = nb; p.nseg = 1; p.N = N; p.ncols = ncols; p.ld = ld;
+        return p;
+    };
+    auto bwd_params = [&](float* Z, int ny) {
+        Prop1P p; memset(&p, 0, sizeof p);
+        const int nseg = nb / ny;
+        for (int k = 0; k < nb; ++k) { p.Sf[k] = frag[4 + k]; p.src[k] = Z + (size_t)(1 + k) * PS; }
+        for (int y = 0; y < ny; ++y) {
+            p.out[y] = y == 0 ? Z : dX + (size_t)(y - 1) * PS;
+            if (y == 0) { p.add0[y] = Z; p.coef0[y] = 1.f; }
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int k = y * nseg + sg;
+                if (k & 1) { p.add1[y] = Z + (size_t)(1 + k) * PS; p.coef1[y] = -1.f; }      // (one T2 block per group at most)
+            }
+        }
+        p.ny = ny; p.nseg = nseg; p.N = N; p.ncols = ncols; p.ld = ld;
+        return p;
+    };
+    printf("N=%d ncols=%d NF=%d reps=%d (plane %.1f MB, %d rotating sets)\n", N, ncols, NF, reps, PS * 4 / 1e6, NSET);
+    // ---- baseline: fused two-hop kernels (feature recursion; numerically the same planes)
+    if (N <= PROP2_MAX_N) {
+        CK(reset());
+        Prop2P q; q.Sf[0] = frag[0]; q.Sf[1] = frag[2]; q.base = dZ; q.extra = nullptr; q.PS = PS; q.ld = ld; q.N = N; q.ncols = ncols;
+        CK(launch_prop2_fwd(q, 0));
+        CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
+        const double ef = check_fwd();
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) { q.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_fwd(q, 0)); }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  prop2_fwd (2 serial hops)           err %.2e   %.1f us\n", ef, 1e3 * ms / reps);
+        CK(reset());
+        q.Sf[0] = frag[4]; q.Sf[1] = frag[6]; q.extra = dX;
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) { q.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_bwd(q, 0)); }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  prop2_bwd (2 serial hops)                          %.1f us\n", 1e3 * ms / reps);
+    }
+    const int cts[3] = {2, 3, 4};
+    for (int stream = 0; stream < 2; ++stream)
+        for (int ci = 0; ci < 3; ++ci) {
+            const int ct = cts[ci];
+            if (NF > 8 && (ct != 2 || !stream)) continue;
+            const int nunits = (ncols + 32 * ct - 1) / (32 * ct);
+            const int caps[3] = {0, 64, 128};
+            for (int cpi = 0; cpi < 3; ++cpi) {
+                const int cap = caps[cpi];
+                if (cap && cap >= nunits) continue;
+                // forward
+                CK(reset());
+                Prop1P p = fwd_params(dZ);
+                CK(launch_prop1(p, ct, stream, cap, 0));
+                CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
+                const double ef = check_fwd();
+                CK(hipEventRecord(e0, 0));
+                for (int r = 0; r < reps; ++r) { Prop1P pr = fwd_params(dZ + (size_t)(r % NSET) * ZT); CK(launch_prop1(pr, ct, stream, cap, 0)); }
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  fwd ct=%d stream=%d cap=%3d (%3d x 4 wgs)  err %.2e   %.1f us\n", ct, stream, cap, cap ? cap : nunits, ef, 1e3 * ms / reps);
+                // backward: 4 / 2 / 1 groups
+                for (int ny = 4; ny >= 2; ny >>= 1) {
+                    CK(reset());
+                    Prop1P b = bwd_params(dZ, ny);
+                    CK(launch_prop1(b, ct, stream, cap, 0));
+                    CK(hipMemcpy(got.data(), dZ, PS * 4, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(gx.data(), dX, (size_t)3 * PS * 4, hipMemcpyDeviceToHost));
+                    const double eb = check_bwd(ny - 1);
+                    CK(reset());
+                    CK(hipEventRecord(e0, 0));
+                    for (int r = 0; r < reps; ++r) { Prop1P br = bwd_params(dZ + (size_t)(r % NSET) * ZT, ny); CK(launch_prop1(br, ct, stream, cap, 0)); }
+                    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    printf("  bwd ct=%d stream=%d cap=%3d groups=%d x %d blocks   err %.2e   %.1f us\n", ct, stream, cap, ny, nb / ny, eb, 1e3 * ms / reps);
+                }
+            }
+        }
+    return 0;
+}
