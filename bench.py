@@ -203,7 +203,7 @@ def self_launch(args):
 
 
 def mform_on():
-    return os.environ.get("MCRN_MFORM", "1") != "0"
+    return os.environ.get("MCRN_MFORM", "0") == "1"     # opt-in (engine.hip plan_model): measured slower at METR-LA
 
 
 def prop_kernel_name(cfg, dtype):
@@ -391,6 +391,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the step's one collective, alone: all-reduce(sum) of a buffer of the flat gradient bucket's size over RCCL (N > 1)
+    allreduce_us, bucket_bytes = None, int(tr.flat_g.numel() * 4)
+    if world > 1:
+        probe = torch.zeros_like(tr.flat_g)
+        for _ in range(5):
+            dist.all_reduce(probe)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        allreduce_us = round(1e6 * (time.perf_counter() - t0) / 20, 2)
+        del probe
     tr.batches_seen = args.batches_seen
     loss = torch.zeros((), device=device)
     for _ in range(args.warmup):
@@ -477,6 +490,7 @@ def main():
             "value": round(val, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
             "backend": "rccl" if world > 1 else "single-process", "world_size": world, "rccl_ranks_seen": ranks_seen,
+            "allreduce_us": allreduce_us, "allreduce_bytes": bucket_bytes,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} "
                                    f"mem={cfg['M']}x{cfg['D']} cheb_k=3, per-GPU batch {B}, full train step "

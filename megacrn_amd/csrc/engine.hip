@@ -201,6 +201,20 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
             ++g_prof.n;                                                                       \
         }                                                                                     \
     } while (0)
+// the same for launches whose parameter block Q carries ev0 / ev1: the two events are attached to the dispatch itself
+// (hipExtLaunchKernelGGL), so their elapsed time is the kernel's own begin -> end, as rocprofv3 reports it
+#define MCRN_PROF_WRAP_EXT(ROLE, Q, LAUNCH, EXEC, ALG)                                         \
+    do {                                                                                      \
+        ++g_launches;                                                                         \
+        const bool prof__ = g_prof.role == (ROLE) && g_prof.n < Prof::MAXEV;                  \
+        if (prof__) { (Q).ev0 = g_prof.ev[2 * g_prof.n]; (Q).ev1 = g_prof.ev[2 * g_prof.n + 1]; } \
+        CK(LAUNCH);                                                                           \
+        if (prof__) {                                                                         \
+            g_prof.exec_flops += (EXEC);                                                      \
+            g_prof.alg_flops += (ALG);                                                        \
+            ++g_prof.n;                                                                       \
+        }                                                                                     \
+    } while (0)
 static inline int prop_small(const PropP& p, int nbatch, int role, double alg, hipStream_t st) {
     const double ex = 2.0 * p.N * (double)p.N * p.ncols * nbatch * p.nseg;
     MCRN_PROF_WRAP(role, launch_prop_small(p, nbatch, st), ex, alg > 0 ? alg : ex);
@@ -465,10 +479,13 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
         } else cfg = bf16_cfg_prior(p, nsplit);
     }
     const bool prof = g_prof.role == (prof_role >= 0 ? prof_role : role) && g_prof.n < Prof::MAXEV;
-    if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
+    const bool ext = prof && !bf16_cfg_is_sk(cfg);          // events attached to the dispatch (the stream-K launcher records around it)
+    if (ext) { p.ev0 = g_prof.ev[2 * g_prof.n]; p.ev1 = g_prof.ev[2 * g_prof.n + 1]; }
+    else if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
     CK(launch_gemm_bf16(p, btr, cfg, nsplit, role, st));
+    p.ev0 = p.ev1 = nullptr;
     if (prof) {
-        CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
+        if (!ext) CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
         const double ex = 2.0 * p.M * (double)p.N * (double)p.nseg * p.seg_len;
         g_prof.exec_flops += ex;
         g_prof.alg_flops += alg > 0 ? alg : ex;
@@ -580,6 +597,7 @@ static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, in
     Shp t = s;
     t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false;
     Prop2P q;
+    q.ev0 = q.ev1 = nullptr;
     q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
     const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
     MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
@@ -730,7 +748,7 @@ static int prop1_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
     q.ny = nb; q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld;
     const Prop1Cfg& c = prop1_cfg();
     const double alg = nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, ex = nb * 2.0 * (double)s.N * s.N * (double)s.ld;
-    MCRN_PROF_WRAP(ROLE_PROP, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
+    MCRN_PROF_WRAP_EXT(ROLE_PROP, q, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
     return 0;
 }
 // backward: dP[0] += sum_k A_k^T dP[1 + k] (- dP[2] - dP[4]: the "- I" of the T2 blocks); the nb blocks are dealt to ny groups,
@@ -772,9 +790,10 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
+        q.ev0 = q.ev1 = nullptr;
         const double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
         const double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
-        MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), ex, alg);
+        MCRN_PROF_WRAP_EXT(ROLE_PROP, q, launch_prop2_fwd(q, st), ex, alg);
         return 0;
     }
     if (use_prop_small(u, s) && aligned16(Z)) {
@@ -936,6 +955,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
+        q.ev0 = q.ev1 = nullptr;
         q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         if (used_dT) *used_dT = 1;
         const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
@@ -1266,6 +1286,16 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
     return 0;
 }
 
+// float4 forms of the element-wise GRU backward kernels: H % 4 == 0 and every pointer 16-byte aligned (the plane row stride Cp
+// and the plane stride PS are multiples of 4 floats by construction)
+template <class... Ps>
+static inline bool cell_bwd_vec(const Shp& s, Ps... ptrs) {
+    static const bool off = getenv("MCRN_CELL_BWD_VEC") && atoi(getenv("MCRN_CELL_BWD_VEC")) == 0;
+    if (off || (s.H & 3) || (s.Cp & 3) || (s.PS & 3)) return false;
+    const void* a[] = {ptrs...};
+    for (const void* p : a) if (p && !aligned16(p)) return false;
+    return true;
+}
 // do_a / do_c: the model's BPTT loops fuse C of step t+1 with A of step t (cell_bwd_ca below) and skip them here
 static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float* Y, const float* zr,
                          const float* hc, const CellW& w, const float* dhn, float* dU, float* dG,
@@ -1288,6 +1318,9 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     const long long dPbS = dPin ? (long long)u.nb * s.PSbh : (long long)u.nb * s.PSb;     // slot of one call
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + dPbS : nullptr, cds, false, dPin, kin,
                       (call0 + 1) * s.B * s.d));
+    if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
+        LAUNCH(k_cell_bwd_b4, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    else
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true, dPin, kin, call0 * s.B * s.d));
     if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, dPin ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
@@ -1301,6 +1334,11 @@ static int cell_bwd_ca(const Shp& s, int xcols, const float* dP, const float* dQ
                        const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
                        float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
                        float* dacc, hipStream_t st) {
+    if (cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc))
+        LAUNCH(k_cell_bwd_ca4, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
+               dTu, xu, s.PS, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
+               Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
+    else
     LAUNCH(k_cell_bwd_ca, dim3(cdiv(s.R * s.H, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
            dTu, xu, s.PS, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
            Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
@@ -1551,7 +1589,7 @@ struct ModelPlan {
     bool bf16;
     int nb, Kp;
     uint16_t *Sstk, *STstk, *sqb;   // sqb: one zero-padded bf16 [Kp][Kp] matrix (S for the T2 product, dT in the backward pass)
-    float *T2[2], *dA, *mu, *mu_part;
+    float *T2[2], *t2part[2], *dA, *mu, *mu_part;
     uint16_t *x0b_e, *x0c_e, *x0b_d, *x0c_d, *dPb_e, *dPb_d;
     uint16_t* xin_b; float* xin_t;   // hoisted input channels: packed bf16 operand [Kp][ncp] and its fp32 product [nb*N][ncp]
     // hoisted backward of the bf16 mode: stack-wide bf16 operands of the adjacency gradient's input part, go-gradient scratch
@@ -1593,11 +1631,14 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         if (P.defer_ds) P.ndef_d = ds_deferred_chunks((int)P.sd.ld);
     }
     {
-        // matrix-form Chebyshev terms (prop_mform.h), the default of the bf16x3 sessions on graphs of N <= 352: every AGCN
-        // call is one single-hop product over nb independent row blocks (MCRN_MFORM=0: the fused two-hop feature recursion)
-        static const bool mform_off = getenv("MCRN_MFORM") && atoi(getenv("MCRN_MFORM")) == 0;
+        // matrix-form Chebyshev terms (prop_mform.h) for the bf16x3 sessions on graphs of N <= 352: every AGCN call is one
+        // single-hop product over nb independent row blocks instead of the fused two-hop feature recursion.  OPT-IN
+        // (MCRN_MFORM=1), parity-tested: measured SLOWER at METR-LA (9 500 vs 10 560 samples/s, profiles/r4/experiments.md):
+        // twice the workgroups each load the full 200 KB fragment image of their block for ONE hop instead of two, and 272 /
+        // 528 workgroups of 7 waves are two rounds on 256 CUs where the fused kernel runs one.
+        static const bool mform_on = getenv("MCRN_MFORM") && atoi(getenv("MCRN_MFORM")) == 1;
         static const bool fused_on = getenv("MCRN_AGCN_FUSED") && atoi(getenv("MCRN_AGCN_FUSED")) == 1;
-        P.mform = !mform_off && !fused_on && !P.defer_ds && d->precision == MCRN_BF16X3 && K <= 3 &&
+        P.mform = mform_on && !fused_on && !P.defer_ds && d->precision == MCRN_BF16X3 && K <= 3 &&
                   prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
         P.se.mform = P.sd.mform = P.mform;
     }
@@ -1659,7 +1700,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.nb = 2 * (K - 1); P.Kp = (N + 63) & ~63;
-    P.Sstk = P.STstk = P.sqb = nullptr; P.T2[0] = P.T2[1] = P.dA = P.mu = P.mu_part = nullptr;
+    P.Sstk = P.STstk = P.sqb = nullptr; P.T2[0] = P.T2[1] = P.t2part[0] = P.t2part[1] = P.dA = P.mu = P.mu_part = nullptr;
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
     P.xin_b = nullptr; P.xin_t = nullptr;
     P.Pb_e = P.Pb_d = nullptr;
@@ -1697,6 +1738,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
         P.sqb = b.take<uint16_t>((size_t)P.Kp * P.Kp);
         for (int i = 0; i < 2; ++i) P.T2[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;
+        for (int i = 0; i < 2; ++i) P.t2part[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;   // second K split of the N^3 products
         P.dA = b.take<float>((size_t)P.nb * N * P.ldS);
         const long long ldm = P.se.ld > P.sd.ld ? P.se.ld : P.sd.ld;
         P.mu = b.take<float>((size_t)2 * (d->T_in > d->T_out ? d->T_in : d->T_out) * ldm);
@@ -1759,6 +1801,13 @@ static Sup model_sup(const ModelPlan& P, int N) {
     return u;
 }
 
+// K splits of the N x N x N products of the T2 matrices and of their chain rule: 2 when the unsplit product leaves more than
+// a third of the CUs without a tile (and K is long enough for the launcher to make exactly 2, see bf16_eff_splits)
+static int t2_splits(int N) {
+    static const bool off = getenv("MCRN_T2_SPLIT") && atoi(getenv("MCRN_T2_SPLIT")) == 0;
+    const long long tiles = (long long)cdiv(N, 256) * cdiv(N, 128);
+    return !off && !bf16_cfg_is_sk(g_force_cfg_bf16) && tiles <= 170 && N >= 512 && bf16_eff_splits(1, N, 2) == 2 ? 2 : 1;
+}
 // MCRN_BF16, once per forward: the stacked bf16 operands.  T2(S) = 2 S S - I (model/MegaCRN.py:20-22) is itself a
 // bf16-resident product: A = the S block of the stack just built (rows, K-contiguous), B = the same block read as [k][n].
 static int build_stacks(const ModelPlan& P, const Sup& u, int N, int K, hipStream_t st) {
@@ -1782,8 +1831,18 @@ static int build_stacks(const ModelPlan& P, const Sup& u, int N, int K, hipStrea
             q.B = P.sqb; q.ldb = P.Kp; q.N = (N + 7) & ~7;        // columns N .. are zero padding
             q.nseg = 1; q.seg_len = N;
             q.C = P.T2[sidx]; q.cm = rm_plain(P.ldS); q.alpha = 2.f;
+            // N x N output = 120 tiles of 256 x 128 at N = 1843 (half a chip, 40 - 46 us per product in round 3): K is split in
+            // two, the second half lands in a scratch matrix that the "- I" pass folds in
+            const int ns = t2_splits(N);
+            if (ns == 2) {
+                q.slab = P.t2part[0] - P.T2[sidx];
+                CKI(bf16_gemm(q, true, 2, ROLE_MISC, 0, st));
+                LAUNCH(k_fold_splits, dim3(cdiv((long long)N * P.ldS, 256)), dim3(256), 0, st, P.T2[sidx], (const float*)P.t2part[0],
+                       (const float*)nullptr, P.ldS, N, 1);
+            } else {
             CKI(bf16_gemm(q, true, 1, ROLE_MISC, 0, st));
             LAUNCH(k_sub_eye, dim3(cdiv(N, 256)), dim3(256), 0, st, P.T2[sidx], P.ldS, N);
+            }
             CKI(put(P.T2[sidx], blk + 1));
         }
     }
@@ -1803,13 +1862,15 @@ static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream
         }
         const uint16_t* Sb = P.Sstk + (long long)(2 * sidx) * N * P.Kp;          // S rows
         const uint16_t* STb = P.STstk + (long long)(2 * sidx) * P.Kp;            // S^T rows (row stride nb*Kp)
+        const int ns = t2_splits(N);      // 2: the second K half of each product lands in a scratch matrix, folded in below
         {   // dS += 2 dT S^T :  B(k, n) = S[n][k]  ->  NT with B = S rows
             Bf16GemmP q = bgp(u);
             q.A = dTb; q.am = rm_plain(P.Kp); q.M = N;
             q.B = Sb; q.bm = rm_plain(P.Kp); q.N = N;
             q.nseg = 1; q.seg_len = N;
             q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
-            CKI(bf16_gemm(q, false, 1, ROLE_MISC, 0, st));
+            if (ns == 2) { q.slab = P.t2part[0] - dS; q.cin_first_only = 1; }
+            CKI(bf16_gemm(q, false, ns, ROLE_MISC, 0, st));
         }
         {   // dS += 2 S^T dT :  A = S^T rows, B = dT as [k][n]
             Bf16GemmP q = bgp(u);
@@ -1817,8 +1878,12 @@ static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream
             q.B = dTb; q.ldb = P.Kp; q.N = (N + 7) & ~7;
             q.nseg = 1; q.seg_len = N;
             q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
-            CKI(bf16_gemm(q, true, 1, ROLE_MISC, 0, st));
+            if (ns == 2) { q.slab = P.t2part[1] - dS; q.cin_first_only = 1; }
+            CKI(bf16_gemm(q, true, ns, ROLE_MISC, 0, st));
         }
+        if (ns == 2)
+            LAUNCH(k_fold_splits, dim3(cdiv((long long)N * P.ldS, 256)), dim3(256), 0, st, dS, (const float*)P.t2part[0],
+                   (const float*)P.t2part[1], P.ldS, N, 0);
     }
     return 0;
 }

@@ -29,6 +29,7 @@
 // transposed adjacency (backward propagation) or one AGCN call (deferred adjacency gradient).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "gemm_bf16_api.h"
@@ -655,6 +656,10 @@ static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st
         attr_set = true;
     }
     (void)hipGetLastError();
+    if (p.ev0 && p.ev1)
+        hipExtLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st,
+                              (hipEvent_t)p.ev0, (hipEvent_t)p.ev1, 0, p);
+    else
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
     return hipGetLastError();
 }
@@ -672,6 +677,10 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
         attr_set = true;
     }
     (void)hipGetLastError();
+    if (p.ev0 && p.ev1)
+        hipExtLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st,
+                              (hipEvent_t)p.ev0, (hipEvent_t)p.ev1, 0, p);
+    else
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }

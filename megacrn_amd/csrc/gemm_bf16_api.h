@@ -48,6 +48,10 @@ struct Bf16GemmP {
     float* sk_ws;             // one BM x BN fp32 partial tile per workgroup
     int* sk_flag;             // one word per workgroup: epoch of the partial it last published
     int sk_epoch;
+    // host side only (bench.py's roofline leg): when set, the launch attaches these two events to the dispatch itself
+    // (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end - what rocprofv3 reports - instead
+    // of the span between two separately recorded event packets (~3 us longer per launch)
+    void *ev0, *ev1;
 };
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st

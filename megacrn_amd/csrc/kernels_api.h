@@ -4,6 +4,7 @@
 // prop_unit.hip: prop_small.h; dgrad_unit.hip: dgrad_stream.h), each of which also includes this file for the structs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -96,6 +97,7 @@ struct Prop2P {
     float* extra;               // backward: support 1 stores S_2^T d1t_2 here (consumers add it to dP[0])
     long long PS, ld;
     int N, ncols;
+    void *ev0, *ev1;            // host side only: events attached to the dispatch itself (roofline leg, see Bf16GemmP); nullptr otherwise
 };
 
 // matrix-form single-hop propagation (prop_mform.h): group y (grid.y) multiplies the blocks y*nseg .. y*nseg + nseg - 1
@@ -108,6 +110,7 @@ struct Prop1P {
     float coef0[4], coef1[4];   // ... and their factors (+1: the accumulating plane, -1: the "- I" of a T2 block)
     int ny, nseg, N, ncols;
     long long ld;
+    void *ev0, *ev1;            // host side only (see Prop2P)
 };
 
 struct DsP {

@@ -639,6 +639,66 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
     dacc[i] = g * rr;
 }
 
+// ---- float4 forms of B and CA (H % 4 == 0; every row stride here is a multiple of 4 floats and every base 16-byte aligned):
+// one thread = 4 consecutive state channels of a row, 16-byte loads / stores, the per-row quantities (go symbol) once per quad
+static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+static __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__global__ void k_cell_bwd_b4(const float* __restrict__ dy0, const float* __restrict__ dy0x, int nx, long long xs, long long ldy,
+                              const float* __restrict__ z0, long long ldz, const float* __restrict__ zr, int H,
+                              long long R, float* __restrict__ dG, float* __restrict__ dacc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H4 = H >> 2;
+    if (i >= R * H4) return;
+    const int c = 4 * (int)(i % H4);
+    const long long r = i / H4;
+    float4 dzh = ld4(dy0 + r * ldy + c);
+    for (int e = 0; e < nx; ++e) dzh = add4(dzh, ld4(dy0x + e * xs + r * ldy + c));
+    const float4 h = ld4(z0 + r * ldz + c), z = ld4(zr + r * 2 * H + c), a = ld4(dacc + r * H + c);
+    st4(dG + r * 2 * H + c, make_float4(dzh.x * h.x * z.x * (1.f - z.x), dzh.y * h.y * z.y * (1.f - z.y),
+                                        dzh.z * h.z * z.z * (1.f - z.z), dzh.w * h.w * z.w * (1.f - z.w)));
+    st4(dacc + r * H + c, make_float4(a.x + dzh.x * z.x, a.y + dzh.y * z.y, a.z + dzh.z * z.z, a.w + dzh.w * z.w));
+}
+__global__ void k_cell_bwd_ca4(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
+                               const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, int xcols, long long ld,
+                               const float* __restrict__ dout_bt, long long out_sb, long long out_sn, int use_next,
+                               const float* __restrict__ Wp, int od, float* __restrict__ dgo_rows, int B,
+                               const float* __restrict__ z0, long long ldz, const float* __restrict__ zr,
+                               const float* __restrict__ hc, int H, long long R,
+                               float* __restrict__ dU, float* __restrict__ dG, float* __restrict__ dacc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H4 = H >> 2;
+    if (i >= R * H4) return;
+    const int c = 4 * (int)(i % H4);
+    const long long r = i / H4;
+    float4 a = ld4(dz0 + r * ld + c);
+    for (int e = 0; e < nzx; ++e) a = add4(a, ld4(dz0x + e * xs + r * ld + c));
+    float4 g = add4(ld4(dacc + r * H + c), a);
+    if (Wp) {
+        const int n = (int)(r / B), b = (int)(r % B);
+        for (int j = 0; j < od; ++j) {
+            float go = dout_bt[b * out_sb + n * out_sn + j];
+            if (use_next) {
+                float x = dz0[r * ld + H + j] + dy0[r * ld + H + j];
+                if (H + j < xcols) {
+                    for (int e = 0; e < nzx; ++e) x += dz0x[e * xs + r * ld + H + j];
+                    for (int e = 0; e < nyx; ++e) x += dy0x[e * xs + r * ld + H + j];
+                }
+                go += x;
+            }
+            const float* __restrict__ w = Wp + (long long)j * H + c;       // (a caller's parameter: no alignment assumed)
+            g.x += go * w[0]; g.y += go * w[1]; g.z += go * w[2]; g.w += go * w[3];
+            if (c == 0) dgo_rows[r * od + j] = go;
+        }
+    }
+    const float4 h = ld4(z0 + r * ldz + c), rr = ld4(zr + r * 2 * H + H + c), hv = ld4(hc + r * H + c);
+    st4(dU + r * H + c, make_float4(g.x * (1.f - rr.x) * (1.f - hv.x * hv.x), g.y * (1.f - rr.y) * (1.f - hv.y * hv.y),
+                                    g.z * (1.f - rr.z) * (1.f - hv.z * hv.z), g.w * (1.f - rr.w) * (1.f - hv.w * hv.w)));
+    st4(dG + r * 2 * H + H + c, make_float4(g.x * (h.x - hv.x) * rr.x * (1.f - rr.x), g.y * (h.y - hv.y) * rr.y * (1.f - rr.y),
+                                            g.z * (h.z - hv.z) * rr.z * (1.f - rr.z), g.w * (h.w - hv.w) * rr.w * (1.f - rr.w)));
+    st4(dacc + r * H + c, make_float4(g.x * rr.x, g.y * rr.y, g.z * rr.z, g.w * rr.w));
+}
+
 // dst += a * src   (plane-wise step of the Chebyshev recursion backward for cheb_k > 3: d_{k-2} -= d_k)
 __global__ void k_axpy(float* __restrict__ dst, const float* __restrict__ src, float a, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1090,6 +1150,20 @@ __global__ void k_stack_build(const float* __restrict__ S, long long lds_, int N
 __global__ void k_sub_eye(float* __restrict__ A, long long ld, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) A[(long long)i * ld + i] -= 1.f;
+}
+
+// A (+)= B [+ C]  [- I]   over an N x N matrix of row stride ld: folds the second K split(s) of an N^3 product into the first
+// (fixed order: one writer per element), optionally with the "- I" of T2 = 2 S S - I
+__global__ void k_fold_splits(float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc, long long ld, int N,
+                              int sub_eye) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * ld) return;
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    if (c >= N) return;
+    float v = A[i] + B[i];
+    if (Cc) v += Cc[i];
+    if (sub_eye && r == c) v -= 1.f;
+    A[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------

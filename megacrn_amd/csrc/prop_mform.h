@@ -160,6 +160,9 @@ void prop1_kernel(const Prop1P p) {
             if (e_ != hipSuccess) return e_;                                                              \
             set_ = true;                                                                                  \
         }                                                                                                 \
+        if ((P).ev0 && (P).ev1)                                                                           \
+            hipExtLaunchKernelGGL((prop1_kernel<NF_, CT_, ST_>), GRID, dim3(64 * NF_), lds_, st, (hipEvent_t)(P).ev0, (hipEvent_t)(P).ev1, 0, P); \
+        else                                                                                              \
         hipLaunchKernelGGL((prop1_kernel<NF_, CT_, ST_>), GRID, dim3(64 * NF_), lds_, st, P);             \
     } while (0)
 #define MCRN_PROP1_NF(CT_, ST_, GRID, P)                                                     \

@@ -11,11 +11,14 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_case, relerr, relerr_rows, proto_mismatch_frac, SC_MEAN, SC_STD
+from helpers import load_case, relerr, relerr_rows, proto_gap_check, SC_MEAN, SC_STD
 from oracle import megacrn_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# top-2 prototype indices (helpers.proto_gap_check): a row may differ from the oracle only when the score gap that decides it
+# is below PROTO_GAP x max(1, |score|): 3 x the measured bf16x3 error of the encoder state the scores are computed from
+PROTO_GAP = 3e-5
 
 
 @pytest.fixture(params=["bf16x3", "f32"])
@@ -228,13 +231,15 @@ def test_full_size_metrla_vs_oracle(amd):
         perm = rng.permutation(B)
         o3 = model(dev(x[perm]), dev(ycov[perm]))
     torch.cuda.synchronize()
-    ref, _ = O.model_fwd(P, x, ycov)
+    ref, rcache = O.model_fwd(P, x, ycov)
     for a, b in zip(o1[:3], ref[:3]):
         assert relerr(a.cpu().numpy(), b) < TOL
-    # pos/neg = Memory[top-2 index]: with random-init weights the attention is almost flat, so a handful of
-    # the 13k rows are near-ties that fp32 summation order alone can flip; everything else must match exactly
-    for a, b in zip(o1[3:], ref[3:]):
-        assert proto_mismatch_frac(a.cpu().numpy(), b) < 2e-3
+    # pos/neg = Memory[top-2 index] is index work: bit-exact wherever the oracle's score gap decides the choice by more
+    # than the arithmetic tolerance of the encoder state (PROTO_GAP); only rows inside that gap are excused, and counted
+    bad, excused, rows, worst = proto_gap_check(o1[3].cpu().numpy(), o1[4].cpu().numpy(), rcache["cmem"], PROTO_GAP)
+    print(f"prototype rows: {rows}, excused near-ties: {excused}, mismatches outside the gap: {bad}")
+    assert bad == 0, (bad, excused, rows, worst)
+    assert excused < 0.01 * rows
     for a, b in zip(o1, o2):
         assert torch.equal(a, b), "same inputs, same workspace -> bit-identical"
     for a, b in zip(o1, o3):
@@ -618,8 +623,9 @@ def _train_step_vs_oracle(amd, N, T, H, M, D, B, seed, fp64=True, we_tol=None):
     o, cache = O.model_fwd(Pd, x.astype(dt), ycov.astype(dt), y.astype(dt), teacher)
     for nm, a, b in zip(("output", "h_att", "query"), outs[:3], o[:3]):
         assert relerr(a.detach().cpu().numpy(), b) < TOL, nm
-    for a, b in zip(outs[3:], o[3:]):
-        assert proto_mismatch_frac(a.detach().cpu().numpy(), b) < 2e-3
+    bad, excused, rows, worst = proto_gap_check(outs[3].detach().cpu().numpy(), outs[4].detach().cpu().numpy(), cache["cmem"], PROTO_GAP)
+    assert bad == 0, (bad, excused, rows, worst)
+    assert excused < 0.01 * rows
     (l, *_), d_out, d_q = O.loss_fwd_bwd(tuple(t.astype(np.float32) for t in o), y, SC_MEAN, SC_STD)
     assert abs(loss.item() - l) < TOL * abs(l)
     G, _ = O.model_bwd(d_out.astype(dt), cache, d_query=d_q.astype(dt))
@@ -661,6 +667,14 @@ def test_baseline_config_train_step_vs_oracle(amd, name):
     _train_step_vs_oracle(amd, N, Tr, H, M, D, B, seed=21, we_tol="measured" if N >= 4096 else None)
 
 
+def test_strong_scaling_per_rank_shape_metrla_b8(amd):
+    """The shape ONE rank runs under strong scaling on 8 GPUs (bench.py --scaling strong: METR-LA's batch of 64 split 8 ways,
+    B = 8 per rank: 17 - 22 workgroups per propagation launch instead of 136 - 176): forward, loss and all 14 gradients vs
+    the float64 oracle.  (EXPY-TKY's per-rank shape, B = 4 in the bf16 mode, is a case of test_bf16_mode_train_step_vs_oracle.)"""
+    N, T, H, M, D, _, Tr, _ = BASELINE_SHAPES["metrla"]
+    _train_step_vs_oracle(amd, N, Tr, H, M, D, 8, seed=23)
+
+
 @pytest.mark.parametrize("name", ["pemsbay", "expytky", "syn8192"])
 def test_baseline_config_full_size_properties(amd, name):
     """Full BASELINE batch and sequence length: results are bit-identical across runs on the same workspace, a batch
@@ -692,7 +706,8 @@ def test_baseline_config_full_size_properties(amd, name):
 # ------------------------------------------------------------------------------------------------
 # MCRN_BF16: bf16-resident propagation / adjacency gradient (the large-graph arithmetic), its own tolerance
 # ------------------------------------------------------------------------------------------------
-BF16_TOL = 2e-2        # stated tolerance of the mode (max-norm relative, like TOL): bf16 operands carry 8 mantissa bits
+BF16_TOL = 1e-2        # stated tolerance of the mode (max-norm relative, like TOL): bf16 operands carry 8 mantissa bits;
+                       # measured worst over the cases below 5.3e-3 (`output` at N = 300; gpurun_out/r4_tests_c.log)
 
 
 @pytest.mark.parametrize("N,B,T,H,M,D,cheb_k", [
@@ -779,6 +794,60 @@ def test_bf16_mode_full_size_properties(name):
     assert all(torch.isfinite(t).all() for t in o1)
 
 
+def test_bf16_mode_20_step_trajectory_tracks_bf16x3():
+    """Multi-step evidence for the large-graph arithmetic (the reference trains for up to 200 epochs,
+    model/traintest_MegaCRN.py:109): 20 optimizer steps of FlatTrainer at the EXPY-TKY geometry (N = 1843, T = 6, H = 32,
+    B = 8) from the same initialisation, the same four batches and the same curriculum draws, once in the 1e-4 parity
+    arithmetic (bf16x3) and once in the bf16 mode.  The loss curves must stay within TRAJ_TOL of each other at every step,
+    the parameters after the 20 steps within PARAM_TOL, and the masked MAE of the bf16-mode forward - the metric north_star
+    quotes - within MAE_TOL (relative) of the float64 oracle's on the same weights and inputs."""
+    import megacrn_amd as amd
+    from megacrn_amd.trainer import FlatTrainer
+    N, T, H, M, D, B, STEPS = 1843, 6, 32, 10, 32, 8, 20
+    TRAJ_TOL, PARAM_TOL, MAE_TOL = 1e-3, 2e-2, 1e-4      # measured (round 4): 3.1e-4, 6.5e-3, 1.4e-6
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, seed=41)
+    rng = np.random.default_rng(42)
+    miss = np.float32((0.0 - SC_MEAN) / SC_STD)
+    batches = []
+    for _ in range(4):
+        x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+        y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
+        x[rng.random(x.shape) < 0.08] = miss
+        y[rng.random(y.shape) < 0.08] = miss
+        ycov = np.broadcast_to(((rng.integers(0, 288, (B, 1, 1, 1)) + T + np.arange(T).reshape(1, T, 1, 1)) / 288.0) % 1.0,
+                               (B, T, N, 1)).astype(np.float32)
+        batches.append((dev(x), dev(ycov), dev(y)))
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=3, M=M, D=D, cl_decay=5)       # cl_decay 5: teacher-forcing probability 0.83 at step 0, 0.40 at step 10, 0.08 at step 20
+    curves, finals, maes = {}, {}, {}
+    for mode in ("bf16x3", "bf16"):
+        amd.test_precision = amd._lib.PRECISIONS[mode]
+        model = build(amd, P, m).train()
+        tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
+        np.random.seed(77)
+        curves[mode] = [tr.train_step(*batches[i % 4]).item() for i in range(STEPS)]
+        finals[mode] = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+        if mode == "bf16":          # masked MAE of a forward at the INITIAL weights vs the float64 oracle
+            m0 = build(amd, P, m).eval()
+            with torch.no_grad():
+                out = m0(batches[0][0], batches[0][1])[0].cpu().numpy()
+            xb, cb, yb = (t.cpu().numpy() for t in batches[0])
+            ref = O.model_fwd({k: v.astype(np.float64) for k, v in P.items()}, xb.astype(np.float64), cb.astype(np.float64))[0][0]
+            yt = yb * SC_STD + SC_MEAN
+            mask = (yt != 0).astype(np.float64); mask /= mask.mean()
+            mae = lambda o: float((np.abs(o.astype(np.float64) * SC_STD + SC_MEAN - yt) * mask).mean())
+            maes = dict(bf16=mae(out), oracle=mae(ref), output_relerr=relerr(out, ref))
+    drift = [abs(a - b) / abs(b) for a, b in zip(curves["bf16"], curves["bf16x3"])]
+    pdrift = {k: relerr(finals["bf16"][k], finals["bf16x3"][k]) for k in finals["bf16"]}
+    mae_rel = abs(maes["bf16"] - maes["oracle"]) / maes["oracle"]
+    print("bf16 vs bf16x3, 20 steps: loss drift max %.3e (last %.3e); parameter drift max %.3e (%s); masked MAE bf16 %.6f vs oracle %.6f (rel %.3e), output relerr %.3e"
+          % (max(drift), drift[-1], max(pdrift.values()), max(pdrift, key=pdrift.get), maes["bf16"], maes["oracle"], mae_rel, maes["output_relerr"]))
+    print("loss curve bf16x3:", [round(v, 4) for v in curves["bf16x3"]])
+    assert all(np.isfinite(curves["bf16"])) and curves["bf16x3"][-1] < curves["bf16x3"][0]          # it trains
+    assert max(drift) < TRAJ_TOL, drift
+    assert max(pdrift.values()) < PARAM_TOL, sorted(pdrift.items(), key=lambda kv: -kv[1])[:4]
+    assert mae_rel < MAE_TOL, maes
+
+
 # gradient additivity over half batches, per tensor (max-norm relative): (everything but dWe1 / dWe2, dWe1 / dWe2).
 # dWe1 / dWe2 pass through the row-softmax backward, which on a large, nearly uniform support cancels all but ~1e-3 of
 # dS (DESIGN.md section 2): the fp32 summation ORDER of the adjacency-gradient product (K = 2T*B*Cp, cut differently for a
@@ -788,7 +857,7 @@ def test_bf16_mode_full_size_properties(name):
 # of the transposed propagation; the fp32 partial sums then differ in their last bit, and where such a value is rounded
 # to a bf16 operand (the gradient planes) the rounding can flip (2^-9 relative): additivity holds to the mode's
 # arithmetic (measured 2e-4 .. 5e-4), not to fp32 round-off (7e-6 when both shapes happen to split alike).
-ADD_TOL = {"bf16x3": (1e-4, 1e-4), "bf16": (2e-3, 1e-2)}
+ADD_TOL = {"bf16x3": (1e-4, 1e-4), "bf16": (1e-3, 3e-3)}     # bf16: measured 4.2e-4 / 1.4e-3 (round 4)
 
 
 @pytest.mark.parametrize("name,mode", [("pemsbay", "bf16x3"), ("expytky", "bf16x3"), ("expytky", "bf16"), ("syn8192", "bf16")])
@@ -869,6 +938,12 @@ def test_packed_fp32_erratum_reproducer_and_guard():
     ({"MCRN_WGRAD_STREAM": "0"}, "model_train_step or large_graph"),  # weight gradient through the tiled GEMM + column sums
     ({"MCRN_DS_MERGE": "0"}, "model_train_step or kernel_variants"),  # one adjacency-gradient launch per AGCN call
     ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
+    # matrix-form Chebyshev terms (prop_mform.h, opt-in): single-hop propagation over 4 independent blocks, adjacency gradient on plane 0
+    ({"MCRN_MFORM": "1"}, "model_train_step or model_eval or kernel_variants or large_graph or full_size_metrla or trainer"),
+    ({"MCRN_MFORM": "1", "MCRN_PROP1_STREAM": "0"}, "(model_train_step and metrla) or kernel_variants"),     # register-stationary adjacency fragments
+    ({"MCRN_MFORM": "1", "MCRN_PROP1_CT": "3", "MCRN_PROP1_BWD_NY": "2"}, "(model_train_step and metrla) or kernel_variants"),   # 96-column units, two blocks per backward group
+    ({"MCRN_MFORM": "1", "MCRN_PROP1_CT": "4", "MCRN_PROP1_CAP": "16"}, "(model_train_step and metrla) or kernel_variants"),     # 128-column units, several units per workgroup
+    ({"MCRN_CELL_BWD_VEC": "0"}, "(model_train_step and (metrla or tiny)) or trainer"),   # scalar forms of the element-wise GRU backward kernels
     ({"MCRN_AGCN_FUSED": "1"}, "(model_train_step and metrla) or full_size_metrla"),   # one launch per AGCN call (agcn_fused.h, opt-in)
     ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 1843)"),   # tiled weight pool
     ({"MCRN_HOIST": "0"}, "bf16_mode_train and 1843"),               # bf16 mode without hoisting (all B*Cp columns per step)

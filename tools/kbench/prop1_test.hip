@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
     // ---- baseline: fused two-hop kernels (feature recursion; numerically the same planes)
     if (N <= PROP2_MAX_N) {
         CK(reset());
-        Prop2P q; q.Sf[0] = frag[0]; q.Sf[1] = frag[2]; q.base = dZ; q.extra = nullptr; q.PS = PS; q.ld = ld; q.N = N; q.ncols = ncols;
+        Prop2P q; memset(&q, 0, sizeof q); q.Sf[0] = frag[0]; q.Sf[1] = frag[2]; q.base = dZ; q.extra = nullptr; q.PS = PS; q.ld = ld; q.N = N; q.ncols = ncols;
         CK(launch_prop2_fwd(q, 0));
         CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
         const double ef = check_fwd();
