@@ -100,6 +100,9 @@ def propagation_alg_bytes(cfg, B, dtype):
             out.append(2 * (K - 1) * N * N * 2 + N * B * Hs * 2 + 2 * (K - 1) * N * B * Hs * 2)
         elif dtype == "bf16":     # stacked bf16 adjacency, bf16 input plane, fp32 output planes
             out.append(2 * (K - 1) * N * N * 2 + N * B * C * 2 + 2 * (K - 1) * N * B * C * 4)
+        elif N <= 352 and Hs == H + D and Hs % 64 == 0 and os.environ.get("MCRN_HOIST_FWD", "1") != "0" and not mform_on():
+            # decoder of the small graphs, forward hoisting (engine.hip Shp::hoist_fwd): the per-step launch covers the state channels
+            out.append(2 * N * N * 4 + N * B * Hs * 4 + 2 * (K - 1) * N * B * Hs * 4)
         else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
             out.append(2 * N * N * 4 + N * B * C * 4 + 2 * (K - 1) * N * B * C * 4)
     per_call = sum(out) / 2.0
@@ -304,10 +307,11 @@ def make_trainer(config_name, B, prec, device, rank):
     return tr, batch
 
 
-def secondary_leg(device, steps=4, warmup=2):
+def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True):
     """The north_star figure, driver-timed: forward N x N propagation at N = 1843 (EXPY-TKY shape, B = 32, T = 6, H = 32)
-    in the bf16-resident arithmetic, as a short extra run after the headline measurement (a few seconds)."""
-    name, prec = "expytky", "bf16"
+    in the bf16-resident arithmetic, as a short extra run after the headline measurement (a few seconds).
+    name = "syn8192" (--with-syn): the same leg on BASELINE configs[4], the N = 8192 roofline run."""
+    prec = "bf16"
     cfg = CONFIGS[name]
     B = cfg["B"]
     tr, batch = make_trainer(name, B, prec, device, 0)
@@ -319,10 +323,10 @@ def secondary_leg(device, steps=4, warmup=2):
         tr.train_step(*batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    regimes = regime_legs(tr, batch, B, steps, 1, torch.cuda.synchronize)
-    roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=4)
-    return {**regimes, "what": "forward K-hop propagation at N=1843 (BASELINE configs[3] shape, per-GPU batch 32), the kernel north_star "
-                    "sets the >= 40 % bf16-MFMA target on; measured in this same process after the headline run",
+    regimes = regime_legs(tr, batch, B, min(steps, 6), 1, torch.cuda.synchronize) if regimes else {}
+    roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=4 if name == "expytky" else 1)
+    return {**regimes, "what": f"forward K-hop propagation at N={cfg['N']} (BASELINE configs[{3 if name == 'expytky' else 4}] shape, per-GPU batch {B}), "
+                    "the kernel north_star sets the >= 40 % bf16-MFMA target on; measured in this same process after the headline run",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} mem={cfg['M']}x{cfg['D']} "
                                    f"cheb_k=3, batch {B}, full train step"},
             "dtype": prec, "value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 4),
@@ -346,6 +350,9 @@ def main():
                     help="curriculum position of the first timed step (model/MegaCRN.py:146-147): 0 = every step teacher-forced "
                          "(the start of training); the line also carries value_no_teacher (no step teacher-forced) either way")
     ap.add_argument("--no-regimes", action="store_true", help="skip the no-teacher and evaluation-forward legs")
+    ap.add_argument("--with-syn", action="store_true",
+                    help="third leg: 3 train steps + forward-propagation roofline of the N = 8192 stress shape (BASELINE configs[4]; "
+                         "~35 GB of workspace, about a minute with its one-off tile autotune: opt-in)")
     ap.add_argument("--roles", default="1,2,3,4,5,6,7", help="GEMM roles timed for gemm_roles (diagnostics); 7 = the hoisted once-per-stack\n                    input-channel products of the bf16 mode (absent in the other modes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -441,7 +448,10 @@ def main():
         # the kernel that takes the most time per step, when it is not the propagation
         if roles:
             top = max(roles.items(), key=lambda kv: kv[1]["ms_per_step"])
-            roof["largest_role_by_time"] = {"role": top[0], **top[1]}
+            # its own roofline fractions: algorithmic flops / launch time against the dense MFMA peak of the arithmetic (bf16x3 issues 3
+            # bf16 MFMAs per product: the fraction of the 833 TF it can reach is 3 x this one)
+            roof["largest_role_by_time"] = {"role": top[0], **top[1],
+                                            "frac_of_mfma_peak": round(top[1]["alg_tflops"] * 1e12 / PEAK[dtype], 5)}
         sync_all()
 
     secondary = None
@@ -452,6 +462,15 @@ def main():
             secondary = secondary_leg(device)
         except Exception as e:                      # the headline line must not depend on the extra leg
             secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    tertiary = None
+    if rank == 0 and world == 1 and args.with_syn:
+        torch.cuda.empty_cache()
+        try:
+            tertiary = secondary_leg(device, steps=3, warmup=1, name="syn8192", regimes=False)
+        except Exception as e:
+            tertiary = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -509,6 +528,8 @@ def main():
             out["gemm_roles"] = roles
         if secondary:
             out["secondary"] = secondary
+        if tertiary:
+            out["syn8192"] = tertiary
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

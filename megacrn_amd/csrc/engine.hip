@@ -309,6 +309,12 @@ struct Shp {   // one AGCN / cell geometry
     long long PSbh;               // Kp * ldh: one packed bf16 [Kp][B*H] matrix
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
+    bool hoist_fwd;               // bf16x3, fused two-hop path, H % 64 == 0 (decoder of the small graphs): forward steps whose input channels
+                                  // are known before the stack starts propagate the B*H state columns only (128 units = one round of 256
+                                  // workgroups at METR-LA instead of 88 units of 96 columns: 22.4 -> 17.7 us); their input / pad channels
+                                  // are propagated once per stack (hoist_inputs_small).  state_only: THIS call runs that way.
+    bool state_only;
+    bool hoist_bwd;               // ... and the backward cells of such steps run their transposed chain on the state columns only
     bool mform;                   // bf16x3, N <= 352, fused model path: matrix-form Chebyshev terms (prop_mform.h): planes 1 .. nb are
                                   // single-hop products [S1; 2 S1 S1 - I; S2; 2 S2 S2 - I] x plane 0, the d-grad weights are not folded
 };
@@ -330,6 +336,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.PSbh = (long long)s.Kp * s.ldh;
     s.fused = false;              // (set by plan_model: needs both output widths of the cell and the session precision)
     s.mform = false;              // (set by plan_model)
+    s.hoist_fwd = false; s.state_only = false; s.hoist_bwd = false;
     static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
     s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
@@ -589,15 +596,15 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
 // unfused propagation wrote there, and the adjacency gradient reads those columns.
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b, uint16_t* x0c, uint16_t* Pb, bool packed);
 static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, float* xin_f, hipStream_t st) {
-    if (!s.fused || w <= 0 || T <= 0) return 0;
+    if (!(s.fused || s.hoist_fwd) || w <= 0 || T <= 0) return 0;
     const int ncols = T * s.B * w;
     const int ncp = (ncols + 3) & ~3;
     const long long tot0 = (long long)s.N * ncp;
     LAUNCH(k_pack_cols_f32, dim3(cdiv(tot0, 256)), dim3(256), 0, st, (const float*)Z, s.ZT, s.N, s.ld, s.Cp, col0, w, s.B, T, ncp, xin_f);
     Shp t = s;
-    t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false;
+    t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false; t.hoist_fwd = false; t.state_only = false;
     Prop2P q;
-    q.ev0 = q.ev1 = nullptr;
+    q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
     q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
     const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
     MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
@@ -790,9 +797,14 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
-        q.ev0 = q.ev1 = nullptr;
-        const double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
-        const double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
+        double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
+        double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
+        if (s.state_only) {          // the input / pad channels of this step's planes were propagated once per stack
+            q.cps = s.H / 64; q.nunits = s.B * q.cps; q.cstride = s.Cp;
+            alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
+            ex = alg;
+        }
         MCRN_PROF_WRAP_EXT(ROLE_PROP, q, launch_prop2_fwd(q, st), ex, alg);
         return 0;
     }
@@ -955,11 +967,18 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
-        q.ev0 = q.ev1 = nullptr;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
         q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         if (used_dT) *used_dT = 1;
-        const double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
-        MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
+        double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld, alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
+        if (s.state_only) {
+            // hoisted backward (small graphs): the chain runs on the B*H state columns only - nothing consumes the propagated gradient
+            // of this cell's input channels (its go symbol was known in advance) - and the first hop on the input / pad channels,
+            // d1 += S^T e2, which the adjacency gradient still reads, is a gathered single-hop launch in front of that gradient
+            q.cps = s.H / 64; q.nunits = s.B * q.cps; q.cstride = s.Cp;
+            ex = alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
+        }
+        MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, alg);
     } else if (s.K == 3 && small) {   // (not reached in the matrix form: its branch is the first of this chain)
         PropP q;
         memset(&q, 0, sizeof q);
@@ -985,11 +1004,17 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         }
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
-    const bool ds_small_path = !u.defer && (s.mform ? s.N <= 256 : small) && aligned16(X) && ds_small_enabled();
+    // 256 < N <= 352 (PEMS-BAY): the output-stationary kernel with column groups (ds_wide_kernel) behind the fused two-hop
+    // chain, merged per cell like the N <= 256 one, instead of one tiled split-K GEMM per call (MCRN_DS_WIDE=0)
+    static const bool ds_wide_off = getenv("MCRN_DS_WIDE") && atoi(getenv("MCRN_DS_WIDE")) == 0;
+    const bool wide_ds = !ds_wide_off && s.N > 256 && s.N <= PROP2_MAX_N && (s.mform || fused_bwd) && (s.ld % 4) == 0;
+    const bool ds_small_path = !u.defer && (s.mform ? (s.N <= 256 || wide_ds) : (small || wide_ds)) && aligned16(X) && ds_small_enabled();
     if (cell_ds && cell_ds->nseg > 0 && !ds_small_path)
         // the update call of this cell queued its d1t x0^T / e2 x1^T segments for a merged launch; the gate call must
         // take the same branch, or those contributions to dS would be silently dropped
         FAIL("adjacency gradient: the two AGCN calls of a cell chose different paths (%d segments queued)", cell_ds->nseg);
+    if (s.state_only && !s.mform && !ds_small_path)
+        FAIL("hoisted backward: the adjacency gradient of this call does not run through ds_small / ds_wide (the gathered first hop lives there)");
     if (u.defer) {
         // nothing here: d1t / e2 stay in this call's plane set and are consumed by the deferred launch
     } else if (ds_small_path) {   // output-stationary adjacency-gradient kernel (prop_small.h)
@@ -1022,6 +1047,23 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                 CK(hipEventRecord(g_side.ready[buf], st));
                 CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
                 ds_st = g_side.st;
+            }
+            if (s.state_only && !s.mform) {
+                // first hop of the transposed chain on the input / pad channels of every call of this launch (16 samples' quads
+                // per unit, one group per (call, support)):  d1[:, in] += S^T e2[:, in]
+                Prop1P g;
+                memset(&g, 0, sizeof g);
+                const int ncall = q.nseg / 2;
+                for (int c = 0; c < ncall; ++c)
+                    for (int b = 0; b < 2; ++b) {
+                        const int y = 2 * c + b;
+                        g.Sf[y] = u.Stf[b]; g.src[y] = q.A[b][2 * c + 1];
+                        g.out[y] = const_cast<float*>(q.A[b][2 * c]); g.add0[y] = q.A[b][2 * c]; g.coef0[y] = 1.f;
+                    }
+                g.ny = 2 * ncall; g.nseg = 1; g.N = s.N; g.ncols = (int)s.ld; g.ld = s.ld;
+                g.cstep = s.Cp; g.col0 = s.H; g.nunits = cdiv(s.B, 16);
+                ++g_launches;
+                CK(launch_prop1(g, 2, false, 0, ds_st));
             }
             {
                 hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
@@ -1323,7 +1365,7 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     else
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true, dPin, kin, call0 * s.B * s.d));
-    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, dPin ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, (dPin || s.state_only) ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
     return 0;
@@ -1763,8 +1805,27 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
                         agcn_fused_ok(N, Hd, od + yd, Hd, P.sd.ld, P.sd.Cp) && agcn_fused_ok(N, Hd, od + yd, 2 * Hd, P.sd.ld, P.sd.Cp) &&
                         wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(Hd, od + yd, P.nb, Hd);
         P.se.fused = P.sd.fused = ok;
-        if (ok) {
-            const long long ce = (long long)d->T_in * B * (P.se.Cp - H), cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
+        // forward hoisting of the decoder's input channels on the fused two-hop path (see Shp::hoist_fwd); the encoder gains nothing
+        // from it (4352 and 4096 columns are both one round of 128 - 136 workgroups: profiles/r4/experiments.md)
+        static const bool hf_off = getenv("MCRN_HOIST_FWD") && atoi(getenv("MCRN_HOIST_FWD")) == 0;
+        static const bool p2w_off = getenv("MCRN_PROP2_WIDE") && atoi(getenv("MCRN_PROP2_WIDE")) == 0;      // (use_prop2)
+        // ... where it saves a PASS of the fused kernels: the wide variant (N > 256: 64-column units only) walks the decoder's
+        // 132 units of PEMS-BAY in two passes of 66 workgroups per support and its 128 state-only units in one (54.6 -> 29 us
+        // forward, 65.5 -> 31 us backward in tools/kbench/prop1_test).  At N <= 256 the full width already fits one pass of
+        // 96-column units (METR-LA: 88 units) and the once-per-stack product + the gathered backward hop cost what the shorter
+        // launches return (measured 10 735 samples/s without, 10 659 forward only, 10 326 both: profiles/r4/experiments.md);
+        // MCRN_HOIST_FWD=2 forces it there (tests).
+        static const int hf_env = getenv("MCRN_HOIST_FWD") ? atoi(getenv("MCRN_HOIST_FWD")) : 1;
+        const int NFp = (N + 31) / 32, u2f = cdiv(P.sd.ld, 64), u3f = cdiv(P.sd.ld, 96), ust = B * (Hd / 64);
+        const int passes_full = (NFp <= 8 && u3f <= 128) ? 1 : cdiv(u2f, 128), passes_state = cdiv(ust > 0 ? ust : 1, 128);
+        P.sd.hoist_fwd = !hf_off && !ok && !P.mform && d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.sd.ld, (int)P.sd.ld) &&
+                         !(p2w_off && N > 256) && (Hd % 64) == 0 && P.sd.Cp > Hd && (passes_state < passes_full || hf_env == 2);
+        static const bool hb_off = getenv("MCRN_HOIST_BWD") && atoi(getenv("MCRN_HOIST_BWD")) == 0;
+        static const bool dsw_off = getenv("MCRN_DS_WIDE") && atoi(getenv("MCRN_DS_WIDE")) == 0;
+        static const bool dsm_off = getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0;
+        P.sd.hoist_bwd = P.sd.hoist_fwd && !hb_off && !P.defer_ds && ds_small_enabled() && (N <= 256 || !dsw_off) && !dsm_off;
+        if (ok || P.sd.hoist_fwd) {
+            const long long ce = ok ? (long long)d->T_in * B * (P.se.Cp - H) : 0, cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
             const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 3) & ~3LL) + 4;
             P.xin_f = b.take<float>((size_t)5 * N * ncp);
         }
@@ -1987,6 +2048,10 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const int Ti = d->T_in, To = d->T_out;
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
+    // forward hoisting of the decoder's input channels (Shp::hoist_fwd) only pays when steps beyond the first are teacher-forced
+    // (evaluation and the late curriculum run every step at full width, with no once-per-stack product)
+    bool any_teacher = false;
+    for (int t = 0; t + 1 < To; ++t) any_teacher |= teacher && labels && teacher[t];
     // The step opens with ~40 tiny, mutually independent preparation launches (supports, weight images, input packing:
     // ~0.45 ms of the 6.7 ms METR-LA step, each 5 us of work behind 7 us of launch gap).  Everything that depends on
     // the WEIGHTS and the decoder's inputs only goes to the helper stream and is joined before the first cell.
@@ -2030,7 +2095,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
     CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));   // go = 0 (:182)
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));
-    if ((sd.hoist || sd.fused) && To > 1) {
+    if ((sd.hoist || sd.fused || sd.hoist_fwd) && To > 1) {
         // the go symbol of step t+1 is labels[:, t] wherever step t is teacher-forced (:188-191): known now, so it takes
         // part in the hoisted propagation of the decoder's input channels; the other steps' go columns are zero until
         // their projection writes them (their planes are then propagated per step, below)
@@ -2061,6 +2126,10 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     } else if (se.fused) {
         CKI(hoist_inputs_small(se, u, P.Zenc, P.Yenc, Ti, H, se.Cp - H, P.xin_f, st));
         CKI(hoist_inputs_small(sd, u, P.Zdec, P.Ydec, To, Hd, sd.Cp - Hd, P.xin_f, st));
+    } else if (sd.hoist_fwd && any_teacher) {
+        // decoder input / pad channels of every step in one product (steps whose go symbol is not known yet contribute zeros here
+        // and are propagated at full width below, which rewrites their columns)
+        CKI(hoist_inputs_small(sd, u, P.Zdec, P.Ydec, To, Hd, sd.Cp - Hd, P.xin_f, st));
     }
     CellW we{P.Wf[0], P.Wd[0], p->enc_gate_b, P.Wf[1], P.Wd[1], p->enc_update_b, P.imgf[0], P.imgd[0], P.imgf[1], P.imgd[1]};
     if (wps) { we.wp_g = P.wpimg[0]; we.wp_u = P.wpimg[1]; }
@@ -2080,7 +2149,11 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     if (wps) { wd.wp_g = P.wpimg[2]; wd.wp_u = P.wpimg[3]; }
     for (int t = 0; t < To; ++t) {
         float* Zn = P.Zdec + (t + 1) * sd.ZT;
-        CKI(cell_fwd_core(sd, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
+        // forward hoisting (bf16x3 small graphs): this step's input channels were known when the stack started iff its go symbol
+        // is zero (t = 0) or the label of a teacher-forced step (model/MegaCRN.py:182,188-191)
+        Shp sdt = sd;
+        sdt.state_only = sd.hoist_fwd && any_teacher && (t == 0 || teacher[t - 1]);
+        CKI(cell_fwd_core(sdt, u, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd,
                           P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PSb : nullptr,
                           P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr,
                           lite ? P.Pb_d + (long long)2 * t * PbS_d : nullptr, t > 0,
@@ -2154,10 +2227,17 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     {
         int xu = 0, xg = 0;
         const float *dPprev = nullptr, *dQprev = nullptr;
+        bool prev_hoisted = false;                 // the cell processed just before (t + 1) ran its chain on the state columns only
+        bool any_teacher = false;                  // (as in model_forward: hoisting only when a step beyond the first is teacher-forced)
+        for (int t = 0; t + 1 < To; ++t) any_teacher |= teacher && teacher[t];
         for (int t = To - 1; t >= 0; --t) {
             const bool last = t == To - 1;
             const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
             const int pair = t % ModelPlan::NPAIR;
+            // hoisted backward (small graphs): nothing reads the propagated gradient of this cell's input channels when its go symbol
+            // was known before the stack started - zero (t = 0) or the label of a teacher-forced step (no use_next at t - 1)
+            Shp sdt = sd;
+            sdt.state_only = sd.hoist_bwd && any_teacher && (t == 0 || teacher[t - 1]);
             float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dPp[pair];
             float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQp[pair];
             if (last) {
@@ -2167,17 +2247,17 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             } else {   // C(t+1) + projection backward(t) + A(t) in one launch
                 // the go symbol of step t+1 was this step's projection: its share of the propagated input gradient of cell t+1
                 if (bh && use_next) CKI(go_grad_bf16(sd, u, P.dPin_d, P.kin_d, 2 * (t + 1), P.go_tmp, const_cast<float*>(dQprev), const_cast<float*>(dPprev), od, st));
-                CKI(cell_bwd_ca(sd, bh ? Hd : sd.Cp, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
+                CKI(cell_bwd_ca(sd, (bh || prev_hoisted) ? Hd : sd.Cp, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
                                 (long long)To * N * od, (long long)od, use_next, p->proj_w, od, P.dgo + (long long)t * R * od,
                                 P.Zdec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                                 P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st));
             }
-            CKI(cell_bwd_core(sd, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
+            CKI(cell_bwd_core(sdt, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
                               P.dTu, P.dTg, /*do_a=*/last, /*do_c=*/t == 0, &xu, &xg,
                               P.bf16 ? P.dPb_d + (long long)2 * t * P.nb * (bh ? sd.PSbh : sd.PSb) : nullptr, pair,
                               bh ? P.dPin_d : nullptr, P.kin_d, 2 * t));
-            dPprev = dPt; dQprev = dQt;
+            dPprev = dPt; dQprev = dQt; prev_hoisted = sdt.state_only;
         }
     }
     // Decoder weight/bias/projection gradients depend only on the finished decoder BPTT: run them on the

@@ -98,6 +98,10 @@ struct Prop2P {
     long long PS, ld;
     int N, ncols;
     void *ev0, *ev1;            // host side only: events attached to the dispatch itself (roofline leg, see Bf16GemmP); nullptr otherwise
+    // forward, state columns only (nunits > 0): unit u covers the 64 columns  (u / cps) * cstride + (u % cps) * 64 ..  - the
+    // H = 64 * cps state channels of sample u / cps inside its row of cstride = Cp floats; the input / pad channels of the planes
+    // 1 .. 4 come from a once-per-stack product (engine.hip: hoist_inputs_small)
+    int nunits, cps, cstride;
 };
 
 // matrix-form single-hop propagation (prop_mform.h): group y (grid.y) multiplies the blocks y*nseg .. y*nseg + nseg - 1
@@ -111,6 +115,9 @@ struct Prop1P {
     int ny, nseg, N, ncols;
     long long ld;
     void *ev0, *ev1;            // host side only (see Prop2P)
+    // gathered units (cstep > 4): a unit's 32*CT columns are 8*CT column QUADS cstep floats apart (the d input / pad channels of
+    // consecutive samples, cstep = Cp); unit u starts at column col0 + u * 8*CT * cstep; nunits of them.  cstep = 0 / 4: contiguous.
+    int cstep, col0, nunits;
 };
 
 struct DsP {

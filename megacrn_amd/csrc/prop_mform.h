@@ -75,14 +75,17 @@ void prop1_kernel(const Prop1P p) {
     uint4 ah[PB::NAL], al[PB::NAL];
     const int nseg = p.nseg;
     if (!STREAM && nseg == 1) PB::load_a(pick4(p.Sf, y) + (long long)w * KS * 2 * 64 + lane, ah, al);   // register-stationary over the units
-    const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int cstep = p.cstep > 4 ? p.cstep : 4;       // floats between the column quads of a unit (Prop1P::cstep)
+    const int nunits = p.cstep > 4 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    // column of output slot s = 32 t + cperm of a unit: quad s >> 2, element s & 3 (contiguous units: colbase + s)
+    const int cq0 = (cperm >> 2) * cstep + (cperm & 3);
     float* __restrict__ OUT = pick4(p.out, y);
     const float* __restrict__ ad0 = pick4(p.add0, y);
     const float* __restrict__ ad1 = pick4(p.add1, y);
     const float c0 = pick4(p.coef0, y), c1 = pick4(p.coef1, y);
     for (int unit = u0; unit < u1; ++unit) {
-        const int colbase = unit * 32 * CT;
+        const int colbase = p.cstep > 4 ? p.col0 + unit * 8 * CT * cstep : unit * 32 * CT;
         int ld = (int)p.ld;
         asm volatile("" : "+s"(ld));                   // see MCRN_ROW_OF
         f32x16 acc[CT], adv0[CT];
@@ -99,7 +102,7 @@ void prop1_kernel(const Prop1P p) {
             int tidv = tid;
             MCRN_FRESH(ld); MCRN_FRESH(nlast);
             asm volatile("" : "+v"(tidv));
-            PB::stage(img, pick4(p.src, k), ld, nlast, p.ncols, colbase, tidv);
+            PB::stage(img, pick4(p.src, k), ld, nlast, p.ncols, colbase, tidv, cstep);
             if (seg == 0) {
                 // fp32 addends (the accumulating plane, the "- I" term of a T2 block): clamped, unpredicated loads issued BEFORE
                 // the barrier and the MFMA phase and only consumed by the epilogue, so they fly during both (in the streamed
@@ -108,7 +111,7 @@ void prop1_kernel(const Prop1P p) {
                 auto ldadd = [&](const float* __restrict__ ad, f32x16 (&dst)[CT]) {
 #pragma unroll
                     for (int t = 0; t < CT; ++t) {
-                        const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+                        const int col = min(colbase + 8 * t * cstep + cq0, p.ncols - 1);
                         if (rows_in) {
                             const unsigned o = (unsigned)(row0 * ld + col);
 #pragma unroll
@@ -132,7 +135,7 @@ void prop1_kernel(const Prop1P p) {
         if (ad1) {   // a second addend (two-blocks-per-group variants only) is fetched here, exposed
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+                const int col = min(colbase + 8 * t * cstep + cq0, p.ncols - 1);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[t][v] += c1 * ad1[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
             }
@@ -140,7 +143,7 @@ void prop1_kernel(const Prop1P p) {
         MCRN_FRESH(ld);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            const int col = colbase + 32 * t + cperm;
+            const int col = colbase + 8 * t * cstep + cq0;
             const unsigned o = (unsigned)(row0 * ld + col);
             if (col < p.ncols) {
 #pragma unroll
@@ -182,7 +185,7 @@ static inline hipError_t launch_prop1(const Prop1P& p, int ct, bool stream, int 
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
     if (NF > 8) { ct = 2; stream = true; }
-    const int nunits = (p.ncols + 32 * ct - 1) / (32 * ct);
+    const int nunits = p.cstep > 4 ? p.nunits : (p.ncols + 32 * ct - 1) / (32 * ct);     // (gathered: the caller counted units of 8*ct quads)
     dim3 grid(cap > 0 && cap < nunits ? cap : nunits, p.ny);
     if (NF > 8) {
         switch (NF) {

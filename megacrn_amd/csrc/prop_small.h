@@ -151,15 +151,17 @@ struct PropBlock {
     // The 8 loads are UNCONDITIONAL from clamped in-range addresses and zeroed afterwards: a load under a
     // divergent branch gets its own basic block and (measured with the in-kernel timeline) one full memory
     // round trip each.  Offsets are 32-bit: base lane offset + scalar multiples of the row stride.
+    // cstep: floats between consecutive column QUADS of the unit (4 = contiguous columns; Cp = the gathered form: quad q is the 4
+    // input / pad channels of sample q0 + q, colbase = q0 * Cp + H)
     static __device__ __forceinline__ void stage(uint4* img, const float* __restrict__ X, int ld, int nlast /* N-1 */,
-                                                 int ncols, int colbase, int tid) {
+                                                 int ncols, int colbase, int tid, int cstep = 4) {
         // items = (8*CT column quads) x (4*NF k-groups); CT == 1: half of the threads have no item, CT == 3: a second round
 #pragma unroll
         for (int it0 = 0; it0 < 8 * CT * 4 * NF; it0 += 64 * NF) {
             const int it = it0 + tid;
             if (it >= 8 * CT * 4 * NF) break;
             const int cg = it % (8 * CT), kg = it / (8 * CT);
-            const int col = colbase + 4 * cg;
+            const int col = colbase + cstep * cg;
             const bool cv = col < ncols;              // ncols % 4 == 0: a float4 is all-in or all-out
             const int colc = cv ? col : 0;
             float v[8][4];
@@ -353,10 +355,11 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     MCRN_TL(0, 0);
     PB::load_a(sfw0, ah, al);
     MCRN_TL(0, 1);
-    const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
     for (int unit = u0; unit < u1; ++unit) {
-        const int colbase = unit * 32 * CT;
+        // (state columns only: the unit's 64 columns sit inside one sample's row of cstride floats, see Prop2P)
+        const int colbase = p.nunits > 0 ? (unit / p.cps) * p.cstride + (unit % p.cps) * 32 * CT : unit * 32 * CT;
         int ld = (int)p.ld;
         asm volatile("" : "+s"(ld));                   // see MCRN_ROW_OF
         if (unit > u0) __syncthreads();                // previous unit's hop-2 image fully consumed
@@ -459,10 +462,12 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
     MCRN_TL(1, 0);
     PB::load_a(sfw0, ah, al);
     MCRN_TL(1, 1);
-    const int nunits = (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
     for (int unit = u0; unit < u1; ++unit) {
-        const int colbase = unit * 32 * CT;
+        // (state columns only, see Prop2P: the first hop on the input channels - d1 += S^T e2, which the adjacency gradient reads -
+        //  is a gathered single-hop launch on the helper stream: prop_mform.h, Prop1P::cstep)
+        const int colbase = p.nunits > 0 ? (unit / p.cps) * p.cstride + (unit % p.cps) * 32 * CT : unit * 32 * CT;
         int ld = (int)p.ld;
         asm volatile("" : "+s"(ld));                   // see MCRN_ROW_OF
         if (unit > u0) __syncthreads();
@@ -605,6 +610,10 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
     const int NF = (p.N + 31) / 32;
     int ct, blocks;
     prop2_shape(p.ncols, ct, blocks, NF);
+    if (p.nunits > 0) {             // state columns only: 64-column units by construction
+        const int passes = (p.nunits + 127) / 128;
+        ct = 2; blocks = (p.nunits + passes - 1) / passes;
+    }
     dim3 grid(blocks, 2);
     if (ct == 3) { MCRN_NF_SWITCH8(prop2_fwd_kernel, 3, grid, p) }
     else { MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p) }
@@ -615,6 +624,10 @@ static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {
     const int NF = (p.N + 31) / 32;
     int ct, blocks;
     prop2_shape(p.ncols, ct, blocks, NF);
+    if (p.nunits > 0) {             // state columns only: 64-column units by construction
+        const int passes = (p.nunits + 127) / 128;
+        ct = 2; blocks = (p.nunits + passes - 1) / passes;
+    }
     dim3 grid(blocks, 2);
     if (ct == 3) { MCRN_NF_SWITCH8(prop2_bwd_kernel, 3, grid, p) }
     else { MCRN_NF_SWITCH(prop2_bwd_kernel, 2, grid, p) }
@@ -773,6 +786,119 @@ __global__ __launch_bounds__(64 * NF) void ds_small_kernel(const DsP p) {
 #endif
 #undef MCRN_TLA
 }
+// The same output-stationary adjacency gradient for 256 < N <= 352 (NF = 9 .. 11: PEMS-BAY).  The N x N block no longer fits
+// one workgroup's accumulators (NF x NF fragments = 121 x 16 VGPRs over 11 waves, and the two-operand image of a panel would
+// be 176 KB of LDS), so a workgroup owns NJ = 4 of the NF column fragments (blockIdx.z = column group): wave w accumulates
+// the fragments (w, j0 .. j0 + NJ - 1) in 64 VGPRs, the LDS image holds all NF fragments of the A panel and the NJ fragments
+// of the B panel it needs ((NF + NJ) x 8 KB, double-buffered: 120 KB at NF = 11).  Every thread still fetches its rows of
+// BOTH operands (the rows of B outside the group are not published: their loads hit the lines the group's neighbours use);
+// slab layout, split-K over column chunks, addend-in-accumulator and the one-writer rule are those of ds_small_kernel.
+template <int NF, int NJ>
+__global__ __launch_bounds__(64 * NF) void ds_wide_kernel(const DsP p) {
+    __shared__ uint4 img[2][NF + NJ][2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int sup = blockIdx.y, z = blockIdx.x;
+    const int j0 = blockIdx.z * NJ;                         // first column fragment of this workgroup
+    const int kbeg = z * p.kchunk;
+    const int kend = min(p.ncols, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+    const int npan = (kend - kbeg + 31) >> 5;
+    const int total = npan * p.nseg;
+    const int cq = tid & 7, r0 = tid >> 3;
+    float4 va[4], vb[4];
+    auto fetch = [&](int pn) {
+        const int seg = pn / npan, pi = pn - seg * npan;
+        const int k = kbeg + 32 * pi + 4 * cq;
+        const bool kv = k < kend;
+        const int kc = kv ? k : kbeg;
+        const float* __restrict__ A = sup == 0 ? p.A[0][seg] : sup == 1 ? p.A[1][seg] : sup == 2 ? p.A[2][seg] : p.A[3][seg];
+        const float* __restrict__ B = sup == 0 ? p.B[0][seg] : sup == 1 ? p.B[1][seg] : sup == 2 ? p.B[2][seg] : p.B[3][seg];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r0 + 8 * NF * i, p.N - 1);
+            va[i] = *reinterpret_cast<const float4*>(A + (long long)r * p.ld + kc);
+            vb[i] = *reinterpret_cast<const float4*>(B + (long long)r * p.ld + kc);
+        }
+        if (!kv) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i]; }
+        }
+    };
+    auto publish = [&](int stg) {
+        uint2* g = reinterpret_cast<uint2*>(&img[stg][0][0][0][0]);
+        const int ks = cq >> 2, kq8 = (cq >> 1) & 1, half = cq & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 8 * NF * i;
+            const int fj = r >> 5, slot = (r & 31) + 32 * kq8;
+            const int ps = slot ^ (kq8 << 1) ^ (ks << 2);    // bank-conflict-free slot order (see ds_small_kernel)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const int fi = op ? NF + fj - j0 : fj;       // fragment slot inside the image
+                if (op && (fj < j0 || fj >= j0 + NJ)) continue;
+                const float4 x = op ? vb[i] : va[i];
+                const unsigned h01 = cvt_pk_bf16(x.x, x.y), h23 = cvt_pk_bf16(x.z, x.w);
+                const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
+                const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
+                const int base = ((fi * 2 + ks) * 2) * 64;                        // uint4 index of [fi][ks][hi][0]
+                g[(base + ps) * 2 + half] = make_uint2(h01, h23);
+                g[(base + 64 + ps) * 2 + half] = make_uint2(l01, l23);
+            }
+        }
+    };
+    fetch(0);
+    float* __restrict__ C = (sup == 0 ? p.C[0] : sup == 1 ? p.C[1] : sup == 2 ? p.C[2] : p.C[3]) + (long long)z * p.slab;
+    f32x16 acc[NJ];
+    {
+        const int rows_in = 32 * w + 32 <= p.N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = min(32 * (j0 + j) + l31, p.N - 1);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+                acc[j][v] = C[(long long)(rows_in ? r : min(r, p.N - 1)) * p.ldc + c];
+            }
+        }
+    }
+    publish(0);
+    if (total > 1) fetch(1);
+    __syncthreads();
+    for (int pn = 0; pn < total; ++pn) {
+        const int stg = pn & 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pl = lane ^ (kq << 1) ^ (ks << 2);
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[stg][w][ks][0][pl]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[stg][w][ks][1][pl]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, img[stg][NF + j][ks][0][pl]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, img[stg][NF + j][ks][1][pl]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
+            }
+        }
+        if (pn + 1 < total) {
+            publish(stg ^ 1);
+            if (pn + 2 < total) fetch(pn + 2);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 32 * (j0 + j) + l31;
+        if (c >= p.N) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
+            if (r < p.N) C[(long long)r * p.ldc + c] = acc[j][v];
+        }
+    }
+}
+static const int DS_WIDE_NJ = 4;
 static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int nblk = 2) {
     (void)hipGetLastError();
     const int NF = (p.N + 31) / 32;
@@ -788,7 +914,12 @@ static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int n
         case 5: hipLaunchKernelGGL(ds_small_kernel<5>, grid, dim3(320), 0, st, p); break;
         case 6: hipLaunchKernelGGL(ds_small_kernel<6>, grid, dim3(384), 0, st, p); break;
         case 7: hipLaunchKernelGGL(ds_small_kernel<7>, grid, dim3(448), 0, st, p); break;
-        default: hipLaunchKernelGGL(ds_small_kernel<8>, grid, dim3(512), 0, st, p); break;
+        case 8: hipLaunchKernelGGL(ds_small_kernel<8>, grid, dim3(512), 0, st, p); break;
+        // 256 < N <= 352: column groups of DS_WIDE_NJ fragments (grid.z)
+        case 9: grid.z = (9 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<9, DS_WIDE_NJ>), grid, dim3(576), 0, st, p); break;
+        case 10: grid.z = (10 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<10, DS_WIDE_NJ>), grid, dim3(640), 0, st, p); break;
+        case 11: grid.z = (11 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<11, DS_WIDE_NJ>), grid, dim3(704), 0, st, p); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

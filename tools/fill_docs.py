@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Regenerate the measured tables of README.md, DESIGN.md (section 8) and profiles/r3/README.md from profiles/r3/bench_*.json.
+"""Regenerate the measured tables of README.md, DESIGN.md (section 8) and profiles/r4/README.md from profiles/r4/bench_*.json.
 
-Every generated block sits between the markers  <!-- r3:NAME:begin -->  and  <!-- r3:NAME:end -->  of its document; the
+Every generated block sits between the markers  <!-- r4:NAME:begin -->  and  <!-- r4:NAME:end -->  of its document; the
 prose around the blocks is written by hand.  Usage: python tools/fill_docs.py"""
 import json
 import os
 import re
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-R = os.path.join(ROOT, "profiles", "r3")
+R = os.path.join(ROOT, "profiles", "r4")
 L = lambda c: json.load(open(os.path.join(R, f"bench_{c}.json")))
 m, p, e, s = L("metrla"), L("pemsbay"), L("expytky"), L("syn8192")
-R2 = {"metrla": "9635 / 6.64 ms", "pemsbay": "5727 / 11.17 ms", "expytky": "4003 / 7.99 ms", "syn8192": "114 / 280 ms"}
+R2 = {"metrla": "10539 / 6.07 ms", "pemsbay": "5677 / 11.27 ms", "expytky": "4672 / 6.85 ms", "syn8192": "126 / 254 ms"}     # round 3
 NAMES = [("metrla", "METR-LA N=207 B=64 T=12", m), ("pemsbay", "PEMS-BAY N=325 B=64 T=12", p),
          ("expytky", "EXPY-TKY N=1843 B=32 T=6 H=32", e), ("syn8192", "SYN N=8192 B=32 T=12", s)]
 
@@ -31,14 +31,16 @@ def traffic(d):
 
 
 def table(with_traffic):
-    head = "| config | arithmetic | samples/s | ms/step | launches/step | round 2 (samples/s / step) | forward propagation (dominant kernel), HIP-event time in real steps |"
-    sep = "|---|---|---|---|---|---|---|"
+    head = "| config | arithmetic | samples/s | no teacher forcing | eval forward (samples/s) | ms/step | launches/step | round 3 (samples/s / step) | forward propagation (dominant kernel), dispatch-attached HIP events in real steps |"
+    sep = "|---|---|---|---|---|---|---|---|---|"
     if with_traffic:
         head += " PMC HBM bytes per launch |"
         sep += "---|"
     rows = [head, sep]
     for key, lbl, d in NAMES:
-        row = f"| {lbl} | {d['dtype']} | **{d['value']:.0f}** | {d['ms_per_step']:.2f} | {d['kernel_launches_per_step']} | {R2[key]} | {roof(d)} |"
+        nt, ev = d.get("value_no_teacher"), d.get("eval_samples_per_s")
+        row = (f"| {lbl} | {d['dtype']} | **{d['value']:.0f}** | {'%.0f' % nt if nt else '—'} | {'%.0f' % ev if ev else '—'} | {d['ms_per_step']:.2f} | "
+               f"{d['kernel_launches_per_step']} | {R2[key]} | {roof(d)} |")
         if with_traffic:
             row += f" {traffic(d)} |"
         rows.append(row)
@@ -59,7 +61,7 @@ def cpu():
         c = d.get("cpu_baseline")
         if not c:
             continue
-        out.append(f"* {lbl.split(' ')[0]}: torch-CPU restatement {c['value']:.3g} samples/s on {c['cores']} threads, {c.get('value_1thread', float('nan')):.3g} on one thread"
+        out.append(f"* {lbl.split(' ')[0]}: torch-CPU restatement {c['value']:.3g} samples/s on {c['cores']} threads (best of {c.get('thread_sweep', {})}), {c.get('value_1thread', float('nan')):.3g} on one thread"
                    f" (what the reference pins); numpy port, one thread: {c.get('value_numpy_port_1thread', float('nan')):.3g}")
     return "\n".join(out)
 
@@ -69,7 +71,8 @@ def secondary():
     if not sec:
         return "(no secondary leg in bench_metrla.json)"
     r = sec["roofline"]
-    return (f"`secondary` object of the default bench line (EXPY-TKY shape, bf16 mode, measured in the same run): {sec['value']:.0f} samples/s, "
+    return (f"`secondary` object of the default bench line (EXPY-TKY shape, bf16 mode, measured in the same run): {sec['value']:.0f} samples/s "
+            f"({sec.get('value_no_teacher', float('nan')):.0f} without teacher forcing, eval forward {sec.get('eval_samples_per_s', float('nan')):.0f}), "
             f"{sec['ms_per_step']:.2f} ms/step, forward propagation {r['achieved']:.0f} TF = {100 * r['frac']:.1f} % of 2.5 PF.")
 
 
@@ -85,12 +88,12 @@ BLOCKS = {
 def fill(path):
     t = open(path).read()
     for name, fn in BLOCKS.items():
-        pat = re.compile(rf"(<!-- r3:{name}:begin -->\n).*?(<!-- r3:{name}:end -->)", re.S)
+        pat = re.compile(rf"(<!-- r4:{name}:begin -->\n).*?(<!-- r4:{name}:end -->)", re.S)
         if pat.search(t):
             t = pat.sub(lambda mo: mo.group(1) + fn() + "\n" + mo.group(2), t)
     open(path, "w").write(t)
 
 
-for f in ("README.md", "DESIGN.md", os.path.join("profiles", "r3", "README.md")):
+for f in ("README.md", "DESIGN.md", os.path.join("profiles", "r4", "README.md")):
     fill(os.path.join(ROOT, f))
 print("filled")

@@ -12,5 +12,8 @@ for cfg in metrla pemsbay expytky; do bash tools/prof_stats.sh ${tag}_$cfg --con
 WINDOW_MS=900 bash tools/prof_stats.sh ${tag}_syn8192 --config syn8192 > /dev/null 2>&1
 for cfg in metrla expytky; do bash tools/pmc_traffic.sh ${tag}_$cfg --config $cfg > $out/${tag}_traffic_$cfg.log 2>&1; done
 bash tools/pmc_mfma.sh ${tag}_expytky --config expytky > /dev/null 2>&1
+# the regime training mostly runs (no step teacher-forced: model/MegaCRN.py:146-147 beyond ~30 000 batches): steady kernel table
+bash tools/prof_stats.sh ${tag}_expytky_noteacher --config expytky --batches-seen 1000000 --no-regimes > /dev/null 2>&1
+bash tools/prof_stats.sh ${tag}_metrla_noteacher --config metrla --batches-seen 1000000 --no-regimes --no-secondary > /dev/null 2>&1
 bash tools/pmc_mfma.sh ${tag}_metrla --config metrla > /dev/null 2>&1
 ls $out | grep "^${tag}_\|_${tag}_" | head -60

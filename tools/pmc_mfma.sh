@@ -5,7 +5,7 @@
 # Counters only (--pmc with --kernel-trace; no other trace domain).  usage: tools/pmc_mfma.sh <tag> [bench args]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcm_${tag} -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary "$@" > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcm_${tag} -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-regimes "$@" > /dev/null 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys, os, collections, re
 tag = sys.argv[1]

@@ -2,7 +2,7 @@
 # per-kernel time of a short bench run: rocprofv3 --kernel-trace --stats.  usage (GPU box): tools/prof_stats.sh <tag> [bench args]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag} -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_bench.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag} -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-regimes "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_bench.json 2> /dev/null
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_stats.csv
 t=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_${tag} -name "*kernel_trace.csv" | head -1)
