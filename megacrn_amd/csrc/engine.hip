@@ -371,8 +371,10 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
 static int nslab_S(int N) {
     // N <= 256: one ds_small workgroup per slab; its slab read + write is ~9 us whatever its K range, so fewer,
     // fatter workgroups cost less GPU time (measured METR-LA: 16 -> 7070, 24 -> 8090, 32 -> 8260, 48 -> 8150, 64 -> 8060 samples/s)
-    static const int small = getenv("MCRN_NSLAB_S") ? atoi(getenv("MCRN_NSLAB_S")) : 32;
-    return N <= 256 ? small : N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
+    static const int env = getenv("MCRN_NSLAB_S") ? atoi(getenv("MCRN_NSLAB_S")) : 0;
+    static const int wide = getenv("MCRN_NSLAB_W") ? atoi(getenv("MCRN_NSLAB_W")) : 32;     // 256 < N <= 512 (ds_wide_kernel at N <= 352)
+    const int small = env > 0 ? env : 32;
+    return N <= 256 ? small : N <= 512 ? wide : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
 }
 static const int NSLAB_W = 256;   // slab capacity of the deferred weight gradients (reduced by k_wunprep)
 static const int NSLAB_W_GEMM = 64;   // ... slabs the tiled-GEMM fallback splits K into
@@ -604,7 +606,7 @@ static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, in
     Shp t = s;
     t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false; t.hoist_fwd = false; t.state_only = false;
     Prop2P q;
-    q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
+    q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
     q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
     const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
     MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
@@ -797,7 +799,7 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
-        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
         double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
         double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         if (s.state_only) {          // the input / pad channels of this step's planes were propagated once per stack
@@ -967,7 +969,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
-        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
         q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         if (used_dT) *used_dT = 1;
         double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld, alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
@@ -1427,10 +1429,10 @@ static int transpose(float* dst, long long ldd, const float* src, long long lds_
 // fragment-ordered bf16 hi/lo images of S1, S2, S1^T, S2^T for the adjacency-stationary kernels
 static int build_frags(const float* s1, const float* s2, long long ld, int N, uint4* const* frag, hipStream_t st) {
     if (!frag[0] || N > PROP2_MAX_N) return 0;
-    ++g_launches; CK(launch_sfrag(s1, ld, N, 0, frag[0], st));
-    ++g_launches; CK(launch_sfrag(s2, ld, N, 0, frag[1], st));
-    ++g_launches; CK(launch_sfrag(s1, ld, N, 1, frag[2], st));
-    ++g_launches; CK(launch_sfrag(s2, ld, N, 1, frag[3], st));
+    // all four images in one launch (round 4: four dependent 5 us launches in the step's opening chain before)
+    const float* src[4] = {s1, s2, s1, s2};
+    const int tr[4] = {0, 0, 1, 1};
+    ++g_launches; CK(launch_sfrag_multi(src, tr, frag, 4, ld, N, st));
     return 0;
 }
 // scope guard: contractions issued while it lives use exact fp32 MFMA whatever the session precision

@@ -93,6 +93,7 @@ struct PropP {
 
 struct Prop2P {
     const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
+    const uint4* Mf[2];         // prop2m_fwd_kernel only (prop_mform.h: harness experiment, not in the library): fragments of 2 S1 S1, 2 S2 S2
     float* base;                // plane set (Z for forward, dP for backward)
     float* extra;               // backward: support 1 stores S_2^T d1t_2 here (consumers add it to dP[0])
     long long PS, ld;

@@ -154,6 +154,109 @@ void prop1_kernel(const Prop1P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward propagation with the second Chebyshev term in MATRIX form inside the fused kernel's workgroup shape (round 4):
+//   plane[1+2s] = S_s x0  (fragments of S register-stationary, as in prop2_fwd_kernel)
+//   plane[2+2s] = (2 S_s S_s) x0 - x0   (fragments of M2_s = 2 S_s S_s streamed from L2 through the register ring)
+// Both products read the SAME staged image of x0, so the serial part of prop2_fwd_kernel's second hop - barrier, accumulators ->
+// B image (to_img), barrier: 3.6 of 18 us per workgroup in the in-kernel timeline (profiles/r1/timeline_metrla.txt) - is gone,
+// while the grid stays that of the fused kernel (units x 2 supports: one round).  The planes are the same quantities as the
+// feature recursion's (to rounding), so the backward pass keeps the recursion form (folded d-grad weights, prop2_bwd_kernel).
+// MEASURED, NOT SHIPPED (tools/kbench/prop1_test only - the library does not instantiate it; profiles/r4/experiments.md section 7):
+// correct to 1.3e-6, but at N = 207 the fragments of M2 streamed through the ring cost more than the barrier + to_img they
+// replace (16.7 vs 15.7 us, 23.3 vs 22.3 us per launch); at N = 325, where S is streamed anyway, 28.0 vs 28.8 / 52.0 vs 55.6 us.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NF, int CT>
+__global__ __launch_bounds__(64 * NF) void prop2m_fwd_kernel(const Prop2P p) {
+    using PB = PropBlock<NF, CT>;                      // S: register-stationary (streamed at NF > 8)
+    using PS = PropBlock<NF, CT, true>;                // M2: always streamed
+    constexpr int KS = 2 * NF;
+    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];
+    uint4* const img = prop2_img;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = blockIdx.y;
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int cperm = 4 * (l31 & 7) + (l31 >> 3);
+    const float* __restrict__ X0 = p.base;
+    float* __restrict__ X1 = p.base + (long long)(1 + 2 * s) * p.PS;
+    float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
+    const int row0 = 32 * w + 4 * kq;
+    const bool rows_in = 32 * w + 32 <= p.N;
+    uint4 ah[PB::NAL], al[PB::NAL], dh[PS::NAL], dl[PS::NAL];
+    const uint4* __restrict__ sfw0 = (s == 0 ? p.Sf[0] : p.Sf[1]) + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ mfw = (s == 0 ? p.Mf[0] : p.Mf[1]) + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;
+    const int ks0 = (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS);
+    PB::load_a(sfw0, ah, al);
+    const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
+    const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    for (int unit = u0; unit < u1; ++unit) {
+        const int colbase = p.nunits > 0 ? (unit / p.cps) * p.cstride + (unit % p.cps) * 32 * CT : unit * 32 * CT;
+        int ld = (int)p.ld;
+        asm volatile("" : "+s"(ld));
+        if (unit > u0) __syncthreads();                // previous unit's image fully consumed
+        int nlast = p.N - 1;
+        int tidv = tid;
+        MCRN_FRESH(ld); MCRN_FRESH(nlast);
+        asm volatile("" : "+v"(tidv));
+        PB::stage(img, X0, ld, nlast, p.ncols, colbase, tidv);
+        __syncthreads();
+        f32x16 acc[CT];
+        PB::mma(img, ah, al, acc, lane, sfw, PB::WIDE ? ks0 : 0);
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            if (col < p.ncols) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = acc[t][v];
+            }
+        }
+        // second term: acc = -x0 (the lines were just staged: cache hits), then the M2 block on the same image
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = min(colbase + 32 * t + cperm, p.ncols - 1);
+            if (rows_in) {
+                const unsigned o = (unsigned)(row0 * ld + col);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = -X0[o + (unsigned)(MCRN_ROW_OF(v) * ld)];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = -X0[(unsigned)(min(row0 + MCRN_ROW_OF(v), p.N - 1) * ld + col)];
+            }
+        }
+        PS::template mma<true>(img, dh, dl, acc, lane, mfw, ks0);
+        MCRN_FRESH(ld);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = colbase + 32 * t + cperm;
+            const unsigned o = (unsigned)(row0 * ld + col);
+            if (col < p.ncols) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (rows_in || row0 + MCRN_ROW_OF(v) < p.N) X2[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = acc[t][v];
+            }
+        }
+    }
+}
+static inline hipError_t launch_prop2m_fwd(const Prop2P& p, hipStream_t st) {
+    (void)hipGetLastError();
+    const int NF = (p.N + 31) / 32;
+    int ct, blocks;
+    prop2_shape(p.ncols, ct, blocks, NF);
+    if (p.nunits > 0) {
+        const int passes = (p.nunits + 127) / 128;
+        ct = 2; blocks = (p.nunits + passes - 1) / passes;
+    }
+    dim3 grid(blocks, 2);
+    if (ct == 3) { MCRN_NF_SWITCH8(prop2m_fwd_kernel, 3, grid, p) }
+    else { MCRN_NF_SWITCH(prop2m_fwd_kernel, 2, grid, p) }
+    return hipGetLastError();
+}
+
 #define MCRN_LAUNCH_PROP1(NF_, CT_, ST_, GRID, P)                                                          \
     do {                                                                                                  \
         constexpr size_t lds_ = (size_t)PropBlock<NF_, CT_, ST_>::IMG * sizeof(uint4);                    \

@@ -711,6 +711,10 @@ BF16_TOL = 1e-2        # stated tolerance of the mode (max-norm relative, like T
 
 
 @pytest.mark.parametrize("N,B,T,H,M,D,cheb_k", [
+    (48, 4, 3, 32, 6, 32, 3),        # one K tile per Chebyshev block (nb * ceil(N / 64) = 4 tiles): a 3- or 4-way split request of the
+                                     # transposed propagation is rounded down by the launcher - the consumers must add only the partial
+                                     # planes that were written (round-3 advisor finding: bf16_eff_splits)
+    (60, 3, 2, 12, 6, 8, 2),         # ... cheb_k = 2: two K tiles in all
     (300, 3, 3, 12, 6, 8, 3),        # odd batch: plane rows padded to 8 channels; K tail of 300 = 4 x 64 + 44
     (261, 4, 2, 12, 6, 8, 2),        # cheb_k = 2: two stacked blocks, no T2
     (261, 8, 2, 32, 6, 32, 2),       # cheb_k = 2 at a width the streaming weight pool takes: bf16-resident planes, 2 of them

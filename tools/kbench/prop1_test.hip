@@ -146,6 +146,32 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  prop2_fwd (2 serial hops)           err %.2e   %.1f us\n", ef, 1e3 * ms / reps);
+        {   // matrix-form second term inside the fused kernel's workgroup shape (prop2m_fwd_kernel)
+            CK(reset());
+            Prop2P m = q; m.base = dZ; m.Mf[0] = frag[1]; m.Mf[1] = frag[3];
+            CK(launch_prop2m_fwd(m, 0));
+            CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
+            const double em = check_fwd();
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) { m.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2m_fwd(m, 0)); }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("  prop2m_fwd (S x0 | 2SS x0 - x0, one image)  err %.2e   %.1f us\n", em, 1e3 * ms / reps);
+            if (N <= 352 && ncols % 132 == 0) {          // state columns only (decoder geometry: H = 128 of Cp = 132)
+                m.base = dZ; m.cps = 2; m.cstride = 132; m.nunits = (ncols / 132) * 2;
+                CK(hipEventRecord(e0, 0));
+                for (int r = 0; r < reps; ++r) { m.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2m_fwd(m, 0)); }
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  prop2m_fwd, state columns only (%d units)              %.1f us\n", m.nunits, 1e3 * ms / reps);
+                Prop2P q2 = q; q2.cps = 2; q2.cstride = 132; q2.nunits = (ncols / 132) * 2;
+                CK(hipEventRecord(e0, 0));
+                for (int r = 0; r < reps; ++r) { q2.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_fwd(q2, 0)); }
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  prop2_fwd,  state columns only (%d units)              %.1f us\n", q2.nunits, 1e3 * ms / reps);
+            }
+        }
         CK(reset());
         q.Sf[0] = frag[4]; q.Sf[1] = frag[6]; q.extra = dX;
         CK(hipEventRecord(e0, 0));
@@ -154,6 +180,7 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  prop2_bwd (2 serial hops)                          %.1f us\n", 1e3 * ms / reps);
     }
+    if (getenv("P1_QUICK")) return 0;                  // baselines only
     const int cts[3] = {2, 3, 4};
     for (int stream = 0; stream < 2; ++stream)
         for (int ci = 0; ci < 3; ++ci) {

@@ -39,7 +39,7 @@ for mf, n, k, mfa, busy, gui, wc, wa, wi in sorted(out, reverse=True):
     dur = busy / 32.0
     util = mfa / (dur * 1024.0) if dur else 0.0
     lines.append(f"{n[:72]:72s} | {k:3d} | {mfa:14.0f} | {busy:12.0f} | {dur:9.0f} | {100 * util:5.1f} % | {wa / wc if wc else 0:5.2f} | {wi / wc if wc else 0:5.2f}")
-    if len(lines) > 30:
+    if len(lines) > 80:
         break
 open(f"{root}/mfma_{tag}.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
