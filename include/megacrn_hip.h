@@ -50,7 +50,7 @@ extern "C" {
                           rnn_units in {32, 64, 128} (H + mem_dim for the decoder likewise) the per-step propagation
                           covers the state channels only (the input channels of every step are propagated once per
                           stack) and writes bf16-resident planes that a streaming weight-pool kernel consumes; every
-                          other contraction as MCRN_BF16X3.  Stated tolerance 2e-2 (tests); the large-graph mode. */
+                          other contraction as MCRN_BF16X3.  Stated tolerance 1e-2 (tests: measured 5e-3); the large-graph mode. */
 
 typedef struct mcrn_dims {
     int B;          /* batch */
