@@ -932,6 +932,33 @@ def test_packed_fp32_erratum_reproducer_and_guard():
         print("control (SLP on, packed fp32):", [ln.strip() for ln in r.stdout.splitlines() if "CONC:" in ln])
 
 
+def test_propagation_harness_matches_float64_reference():
+    """tools/kbench/prop1_test: the small-graph propagation kernels launched OUTSIDE the model's launch sequence against a float64
+    CPU product of the same inputs - the harness that exposed the VALU-SGPR -> VMEM hazard of the streamed adjacency fragments
+    (256 < N <= 352: 3e-2 off in the harness while the model-level parity tests passed, profiles/r4/experiments.md section 3).
+    Every printed error - fused two-hop kernels, matrix-form variants with register-stationary and streamed fragments, forward
+    and backward, N = 207 and N = 325 - must be at the bf16x3 level."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kb = os.path.join(root, "tools", "kbench")
+    exe = os.path.join(kb, "prop1_test")
+    if not os.path.exists(exe):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-vectorize", "-o", exe,
+                        os.path.join(kb, "prop1_test.hip")], check=True, timeout=900)
+    for shape, quick in (("207 4352", False), ("325 4352", False), ("325 8448", True)):
+        env = dict(os.environ)
+        if quick:
+            env["P1_QUICK"] = "1"
+        r = subprocess.run([exe] + shape.split() + ["4"], env=env, cwd=kb, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        errs = [float(v) for v in re.findall(r"err ([0-9.e+-]+)", r.stdout)]
+        assert len(errs) >= (2 if quick else 6), r.stdout[-1500:]
+        assert max(errs) < 2e-5, (shape, max(errs), r.stdout[-1500:])
+
+
 # ------------------------------------------------------------------------------------------------
 # A/B knobs read once at library load: every alternative code path stays under the same parity tests (fresh
 # interpreter per knob).  Each line = (environment, pytest -k selection that exercises the path it switches).
