@@ -972,13 +972,13 @@ def test_propagation_harness_matches_float64_reference():
     ({"MCRN_PROP2_WIDE": "0"}, "large_graph"),                       # 256 < N <= 352 through the tiled propagation
     # hoisted decoder input channels on the fused two-hop path (default where it saves a pass: PEMS-BAY at B = 64); forced on for every
     # shape with H % 64 == 0 (= the oracle cases at METR-LA B = 64 / 8 and PEMS-BAY B = 4), forward only, and off
-    ({"MCRN_HOIST_FWD": "2"}, "(model_train_step and metrla) or full_size_metrla or baseline_config_train or strong_scaling or (full_batch_backward and pemsbay)"),
+    ({"MCRN_HOIST_FWD": "2"}, "(model_train_step and metrla) or full_size_metrla or (baseline_config_train and (metrla or pemsbay)) or strong_scaling or (full_batch_backward and pemsbay)"),
     ({"MCRN_HOIST_FWD": "2", "MCRN_HOIST_BWD": "0"}, "(model_train_step and metrla) or (baseline_config_train and pemsbay)"),
     ({"MCRN_HOIST_FWD": "0"}, "full_batch_backward and pemsbay"),
     ({"MCRN_DS_WIDE": "0"}, "large_graph"),                          # 256 < N <= 352: adjacency gradient through the tiled split-K GEMM, one launch per call
     ({"MCRN_T2_SPLIT": "0"}, "bf16_mode_train and 1843"),            # bf16 mode: unsplit N^3 products of T2 = 2 S S - I and of its chain rule
     # matrix-form Chebyshev terms (prop_mform.h, opt-in): single-hop propagation over 4 independent blocks, adjacency gradient on plane 0
-    ({"MCRN_MFORM": "1"}, "model_train_step or model_eval or kernel_variants or large_graph or full_size_metrla or trainer"),
+    ({"MCRN_MFORM": "1"}, "(model_train_step and (metrla or tiny or cheb2)) or (model_eval and metrla) or kernel_variants or large_graph or full_size_metrla"),
     ({"MCRN_MFORM": "1", "MCRN_PROP1_STREAM": "0"}, "(model_train_step and metrla) or kernel_variants"),     # register-stationary adjacency fragments
     ({"MCRN_MFORM": "1", "MCRN_PROP1_CT": "3", "MCRN_PROP1_BWD_NY": "2"}, "(model_train_step and metrla) or kernel_variants"),   # 96-column units, two blocks per backward group
     ({"MCRN_MFORM": "1", "MCRN_PROP1_CT": "4", "MCRN_PROP1_CAP": "16"}, "(model_train_step and metrla) or kernel_variants"),     # 128-column units, several units per workgroup
