@@ -1185,7 +1185,8 @@ static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* d
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
                       int O, float* slabs, hipStream_t st, int* nslab, bool* ones = nullptr,
                       const uint16_t* Xb = nullptr /* bf16-resident planes of these calls */, long long xb_step = 0, long long xb_plane = 0,
-                      const float* Xc = nullptr /* compact input channels of planes 1 .. nb, [T][nb][R][4] */) {
+                      const float* Xc = nullptr /* compact input channels of planes 1 .. nb, [T][nb][R][4] */,
+                      int slab_budget = NSLAB_W /* workgroups of the streaming kernel (= slabs): fewer leave CUs to a concurrent queue */) {
     // ones != null: the caller wants the column sums of dY (bias gradient) as row G*Cp of the slabs when the streaming
     // kernel runs (*ones = true), and computes them itself otherwise
     if (ones) *ones = false;
@@ -1199,7 +1200,8 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
         q.X = Xall; q.step_stride = step_stride; q.PS = s.PS; q.Cp = s.Cp; q.G = s.G; q.T = T; q.R = s.R;
         q.dY = dYall; q.O = O; q.slabs = slabs; q.ones = ones ? 1 : 0;
         if (ones) *ones = true;
-        q.cpt = NSLAB_W / T < 1 ? 1 : NSLAB_W / T;
+        if (slab_budget > NSLAB_W || slab_budget < T) slab_budget = NSLAB_W;
+        q.cpt = slab_budget / T < 1 ? 1 : slab_budget / T;
         if (q.cpt > cdiv(s.R, 32)) q.cpt = (int)cdiv(s.R, 32);
         q.kch = (int)(cdiv(cdiv(s.R, q.cpt), 32) * 32);
         if (T * q.cpt > NSLAB_W) FAIL("weight gradient: %d steps exceed the slab capacity", T);
@@ -2293,9 +2295,17 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     bool on1 = false, on2 = false, on3 = false, on4 = false;
     const bool lite = P.bf16 && P.Pb_e != nullptr;
     const long long PbS_e = (long long)P.nb * N * se.ldh, PbS_d = (long long)P.nb * N * sd.ldh;
-    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d));
+    // Workgroups of the decoder's weight-gradient launches when they run beside the encoder BPTT on the helper stream
+    // (MCRN_WGRAD_DEC_WGS).  At full width (252 workgroups at T = 12) the two launches take every CU for ~0.35 ms and the first
+    // encoder cells of the main queue run at half speed; at 120 they take twice as long on half the chip and the main queue
+    // keeps the other half: METR-LA 10 950 vs 10 700 / 10 630 and 10 780 / 10 805 vs 10 633 / 10 625 samples/s, PEMS-BAY 6 425 vs
+    // 6 314 / 6 299 (two calls; 72 workgroups: slower again - profiles/r4/experiments.md).  The bf16 mode measured no difference
+    // (its helper stream runs beside MFMA-bound products) and keeps the full width.
+    static const int wg_env = getenv("MCRN_WGRAD_DEC_WGS") ? atoi(getenv("MCRN_WGRAD_DEC_WGS")) : 0;
+    const int dec_budget = ws_ != st ? (wg_env > 0 ? wg_env : (P.bf16 ? NSLAB_W : NSLAB_W / 2)) : NSLAB_W;
+    CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     int ns2 = 0;
-    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d));
+    CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     // hoisted backward, adjacency gradient of one cell stack (K-concatenated over every AGCN call); with MCRN_BF16_DS_SIDE=1 the
     // decoder's runs on the helper stream behind its weight gradients and overlaps the encoder BPTT; the encoder's accumulates
     // into the same dA after the join
