@@ -16,6 +16,7 @@
 //   * the column -> lane slot permutation col = 4*(s&7) + (s>>3) makes the staging writes conflict-free.
 // Arithmetic: bf16x3 split (see gemm_bf16x3.h), fp32 accumulate.
 #pragma once
+#include <stdlib.h>
 #include "gemm_bf16x3.h"
 
 namespace mcrn {
@@ -918,7 +919,13 @@ static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int n
         // 256 < N <= 352: column groups of DS_WIDE_NJ fragments (grid.z)
         case 9: grid.z = (9 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<9, DS_WIDE_NJ>), grid, dim3(576), 0, st, p); break;
         case 10: grid.z = (10 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<10, DS_WIDE_NJ>), grid, dim3(640), 0, st, p); break;
-        case 11: grid.z = (11 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<11, DS_WIDE_NJ>), grid, dim3(704), 0, st, p); break;
+        case 11: {
+            // MCRN_DS_WIDE_NJ=6 (measurement): two column groups of 6 fragments instead of three of 4 (96 accumulator VGPRs: 22 spilled dwords)
+            static const bool nj6 = getenv("MCRN_DS_WIDE_NJ") && atoi(getenv("MCRN_DS_WIDE_NJ")) == 6;
+            if (nj6) { grid.z = 2; hipLaunchKernelGGL((ds_wide_kernel<11, 6>), grid, dim3(704), 0, st, p); }
+            else { grid.z = (11 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<11, DS_WIDE_NJ>), grid, dim3(704), 0, st, p); }
+            break;
+        }
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
