@@ -225,6 +225,9 @@ static inline int prop_small(const PropP& p, int nbatch, int role, double alg, h
 // caller has to reason about (every side launch is joined back before the call returns its last kernel).
 struct Side {
     hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr;                   // second helper queue: the decoder's deferred weight gradients (round 4), so that the
+    hipEvent_t fork2, join2;                     // encoder's adjacency-gradient launches are not queued behind ~0.5 ms of them
+    bool any2 = false;
     static const int NSLOT = 6;                  // plane sets: (update, gate) x NPAIR cells of the BPTT loop in flight
     hipEvent_t ready[NSLOT], done[NSLOT], join, fork, mid;
     bool ok = false, pending[NSLOT] = {false, false, false, false, false, false}, any = false;
@@ -244,6 +247,9 @@ static int side_init() {
     CK(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g_side.mid, hipEventDisableTiming));
+    CK(hipStreamCreateWithPriority(&g_side.st2, hipStreamNonBlocking, lo));
+    CK(hipEventCreateWithFlags(&g_side.fork2, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g_side.join2, hipEventDisableTiming));
     g_side.ok = true;
     return 0;
 }
@@ -260,6 +266,11 @@ static int side_guard(int buf, hipStream_t st) {
     return 0;
 }
 static int side_join(hipStream_t st) {
+    if (g_side.ok && g_side.any2) {
+        CK(hipEventRecord(g_side.join2, g_side.st2));
+        CK(hipStreamWaitEvent(st, g_side.join2, 0));
+        g_side.any2 = false;
+    }
     if (g_side.ok && g_side.any) {
         CK(hipEventRecord(g_side.join, g_side.st));
         CK(hipStreamWaitEvent(st, g_side.join, 0));
@@ -271,7 +282,7 @@ static int side_join(hipStream_t st) {
 
 // error paths: forget pending fork/join state (the caller's next call starts clean)
 static void side_reset() {
-    g_side.any = false;
+    g_side.any = false; g_side.any2 = false;
     for (int i = 0; i < Side::NSLOT; ++i) g_side.pending[i] = false;
 }
 // The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
@@ -1630,7 +1641,7 @@ struct ModelPlan {
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
     float *dWq_s, *dMem_s, *dWp_s;
-    float *part, *part2;
+    float *part, *part2, *part3;
     // MCRN_BF16: stacked bf16 adjacency and its transpose, T2 matrices, per-call bf16 operands, adjacency-gradient blocks
     bool bf16;
     int nb, Kp;
@@ -1745,6 +1756,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     int Tm = d->T_in > d->T_out ? d->T_in : d->T_out;
     P.part = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
     P.part2 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);
+    P.part3 = b.take<float>(colsum_part_floats((long long)Tm * R, 2 * Hd) + 1024);   // (second helper queue)
     P.nb = 2 * (K - 1); P.Kp = (N + 63) & ~63;
     P.Sstk = P.STstk = P.sqb = nullptr; P.T2[0] = P.T2[1] = P.t2part[0] = P.t2part[1] = P.dA = P.mu = P.mu_part = nullptr;
     P.x0b_e = P.x0c_e = P.x0b_d = P.x0c_d = P.dPb_e = P.dPb_d = nullptr;
@@ -2271,9 +2283,15 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     float* part_ = P.part;
     if (g_use_side && !g_tuning && g_prof.role < 0) {
         CKI(side_init());
-        CK(hipEventRecord(g_side.fork, st));         // (its own event: ready[0] belongs to the per-call launches of the loops)
-        CK(hipStreamWaitEvent(g_side.st, g_side.fork, 0));
-        ws_ = g_side.st; part_ = P.part2; g_side.any = true;
+        // Second helper queue (MCRN_SIDE2=0: the first one, as before round 4).  On the first queue the encoder's adjacency-
+        // gradient launches waited behind these ~0.5 ms of HBM streaming, the plane-set guards of the main queue behind them.
+        static const bool side2_off = getenv("MCRN_SIDE2") && atoi(getenv("MCRN_SIDE2")) == 0;
+        const bool two = !side2_off && !P.bf16 && !P.defer_ds;
+        hipStream_t hs = two ? g_side.st2 : g_side.st;
+        CK(hipEventRecord(two ? g_side.fork2 : g_side.fork, st));         // (its own event: ready[0] belongs to the per-call launches of the loops)
+        CK(hipStreamWaitEvent(hs, two ? g_side.fork2 : g_side.fork, 0));
+        ws_ = hs; part_ = two ? P.part3 : P.part2;
+        if (two) g_side.any2 = true; else g_side.any = true;
     }
     {   // proj grads: dWp[j][c] = sum_{t,r} dgo[t][r][j] * h'_t[r][c]  (h'_t lives in Zdec[t+1])
         GemmP q = gp();
@@ -2302,7 +2320,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // 6 314 / 6 299 (two calls; 72 workgroups: slower again - profiles/r4/experiments.md).  The bf16 mode measured no difference
     // (its helper stream runs beside MFMA-bound products) and keeps the full width.
     static const int wg_env = getenv("MCRN_WGRAD_DEC_WGS") ? atoi(getenv("MCRN_WGRAD_DEC_WGS")) : 0;
-    const int dec_budget = ws_ != st ? (wg_env > 0 ? wg_env : (P.bf16 ? NSLAB_W : NSLAB_W / 2)) : NSLAB_W;
+    // Round 4, second step: on their OWN queue (Side::st2) they no longer hold up the encoder's adjacency-gradient launches, and
+    // there the narrower the better until they stop fitting the encoder BPTT: 24 workgroups (budget 32) -> METR-LA 11 026 / 10 995
+    // vs 10 781 (one helper queue, 120 workgroups) and 10 633 before; PEMS-BAY 6 314 / 6 276 vs 6 184; 12 workgroups: 9 410.
+    const bool own_queue = g_side.ok && ws_ == g_side.st2;
+    const int dec_budget = ws_ != st ? (wg_env > 0 ? wg_env : (P.bf16 ? NSLAB_W : (own_queue ? 32 : NSLAB_W / 2))) : NSLAB_W;
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     int ns2 = 0;
     CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
@@ -2387,6 +2409,16 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         wu_st = g_side.st; part_u = P.part2;
         if (P.bf16) { wg_st = g_side.st; part_g = P.part2; }
         g_side.any = true;
+        // small graphs with the second helper queue, OPT-IN (MCRN_TAIL2=1: measured neutral, 11 061 / 11 065 vs 11 062 / 11 046 samples/s
+        // at METR-LA): the gate call's weight gradient (130 us) leaves the caller's tail too and runs beside the chain of tiny
+        // launches of the adjacency backward
+        static const bool tail2_on = getenv("MCRN_TAIL2") && atoi(getenv("MCRN_TAIL2")) == 1;
+        static const bool side2_off = getenv("MCRN_SIDE2") && atoi(getenv("MCRN_SIDE2")) == 0;
+        if (!P.bf16 && !P.defer_ds && tail2_on && !side2_off) {
+            CK(hipEventRecord(g_side.fork2, st));
+            CK(hipStreamWaitEvent(g_side.st2, g_side.fork2, 0));
+            wg_st = g_side.st2; part_g = P.part3; g_side.any2 = true;
+        }
     }
     int ns3 = 0;
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], wg_st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh, P.Xp_e));
