@@ -1608,8 +1608,14 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
 }
 static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st, int nslab, float* dbias = nullptr) {
     long long tot = (long long)2 * s.K * s.C * O + (dbias ? O : 0);
-    LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, (long long)(s.G * s.Cp + (dbias ? 1 : 0)) * O, s.d, s.H,
-           s.Cp, s.K, O, dbias);
+    const long long slab = (long long)(s.G * s.Cp + (dbias ? 1 : 0)) * O;
+    static const bool vec_off = getenv("MCRN_WUNPREP_VEC") && atoi(getenv("MCRN_WUNPREP_VEC")) == 0;
+    // four outputs per thread when every 4-group stays inside one row of both layouts and every address is 16-byte aligned
+    if (!vec_off && (O & 3) == 0 && (slab & 3) == 0 && (((uintptr_t)dW | (uintptr_t)slabs | (uintptr_t)dbias) & 15) == 0) {
+        LAUNCH(k_wunprep4, dim3(cdiv(tot, 256)), dim3(1024), 0, st, dW, slabs, nslab, slab, s.d, s.H, s.Cp, s.K, O, dbias);
+        return 0;
+    }
+    LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, slab, s.d, s.H, s.Cp, s.K, O, dbias);
     return 0;
 }
 

@@ -32,6 +32,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_bf16_api.h"
 
 namespace mcrn {
@@ -53,6 +54,19 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                  : "memory");
 }
 #define MCRN_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// -DMCRN_BF16_ABL=bits (tools/kbench/bf16_gemm_test only; results are wrong by construction): 1 = no operand DMA inside the
+// K loop, 2 = fragments read from LDS once, 4 = no MFMA.  What a K loop costs without one of its three streams.
+#ifndef MCRN_BF16_ABL
+#define MCRN_BF16_ABL 0
+#endif
+#if MCRN_BF16_ABL & 8
+// bit 8: workgroup 0 records the shader-clock counter and the 100 MHz wall clock at both ends of the kernel (the clock the
+// chip really runs at under this load = d(clock64) / d(wall_clock64) x 100 MHz)
+__device__ unsigned long long g_bf16_clk[4];
+#define MCRN_CLK_PROBE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_bf16_clk[2 * (i)] = clock64(); g_bf16_clk[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define MCRN_CLK_PROBE(i)
+#endif
 
 // ---- pieces shared by the two kernels ------------------------------------------------------------------------
 template <int BM, int BN, int BK, int NT, bool BTR>
@@ -124,7 +138,35 @@ struct Bf16Tile {
             if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(Bb, offB[j], sB + j * NT * 16);
         if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; }
     }
+    // The same DMA in PIECES, for K loops that slip them between the MFMAs of the tile being multiplied: a wave that issues
+    // its 6 - 8 pieces back to back waits 60 - 180 cycles per piece for the address path with the matrix pipe idle
+    // (profiles/r4/experiments.md section 13: the loop without its DMA ran 12 - 14 % faster); one piece every few MFMAs
+    // issues in the shadow of the 32-cycle MFMA in flight.   issue_begin ; issue_piece(0 .. NPIECE-1) ; issue_end
+    static constexpr int NPIECE = AJ + BJ;
+    const uint16_t *pcA, *pcB;
+    unsigned pcsA, pcsB;
+    __device__ __forceinline__ void issue_begin(unsigned lds_base, int stg, int wave) {
+        pcA = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
+        pcB = baseB + (long long)iss_seg * stepB_seg + (long long)(iss_lt * BK) * stepB_k;
+        pcsA = lds_base + stg * STAGE + wave * 1024;
+        pcsB = pcsA + ASLOTS * 16;
+    }
+    __device__ __forceinline__ void issue_piece(int J, int wave) {          // J is a constant after unrolling
+        if (J < AJ) {
+            if (ASLOTS % NT == 0 || J * NT + wave * 64 < ASLOTS) glds16(pcA, offA[J], pcsA + J * NT * 16);
+        } else if (J < AJ + BJ) {
+            const int j = J - AJ;
+            if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(pcB, offB[j], pcsB + j * NT * 16);
+        }
+    }
+    __device__ __forceinline__ void issue_end() { if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; } }
 };
+// which DMA piece (if any) follows MFMA number m of a tile's NM: the NP pieces are spread evenly, the first one early
+__device__ __forceinline__ constexpr int bf16_piece_after(int m, int NM, int NP) {
+    // piece q follows MFMA number floor(q * NM / NP) (0-based): q = ceil(m * NP / NM) if that maps back to m
+    const int q = (m * NP + NM - 1) / NM;
+    return (q < NP && q * NM / NP == m) ? q : -1;
+}
 
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); XCD x gets a contiguous
 // range of tiles (bijective for any tile count), walked GM row tiles per column tile: the tiles resident on one XCD
@@ -349,6 +391,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nt) tl.issue(lds_base, s, wave);
     int rd = 0;
+#if MCRN_BF16_ABL & 2
+    bf16x8_t a[2][FM], b[2][FN];
+#endif
     for (int t = 0; t < nt; ++t) {
         // tile t has landed once at most the DMA of the NSTAGE-2 younger tiles remains in flight (steady state);
         // in the tail fewer tiles are in flight: drain
@@ -357,23 +402,78 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         __syncthreads();                                         // tile t visible to all; tile t-1 consumed by all
         const unsigned char* sA = smem_bf16 + rd * T::STAGE;
         const unsigned char* sB = sA + T::ASLOTS * 16;
+        // Wave tiles of 8+ fragments (128 x 64): the DMA pieces go BETWEEN the MFMAs (see Bf16Tile::issue_piece; -5 .. -8 % per
+        // launch).  The 64 x 64 wave tile of the 256 x 128 eight-wave form has only 16 MFMAs per tile for 6 pieces and two
+        // waves per SIMD already overlap each other's issue: it keeps the DMA behind its MFMAs (interleaved: +1 %).
+        constexpr bool ILV = FM * FN >= 8;
+        if constexpr (!ILV) {
 #pragma unroll
-        for (int ks = 0; ks < T::KS; ++ks) {
-            bf16x8_t a[FM], b[FN];
+            for (int ks = 0; ks < T::KS; ++ks) {
+                bf16x8_t a1[FM], b1[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+                for (int i = 0; i < FM; ++i) a1[i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+                for (int j = 0; j < FN; ++j) b1[j] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (t + NSTAGE - 1 < nt) {
-            int wr = rd + NSTAGE - 1;
-            if (wr >= NSTAGE) wr -= NSTAGE;
-            tl.issue(lds_base, wr, wave);                        // refill the stage tile t-1 left (all waves passed the barrier)
+                    for (int j = 0; j < FN; ++j) {
+                        if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(a1[i]), "v"(b1[j])); }
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (!(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt) {
+                int wr = rd + NSTAGE - 1;
+                if (wr >= NSTAGE) wr -= NSTAGE;
+                tl.issue(lds_base, wr, wave);                    // refill the stage tile t-1 left (all waves passed the barrier)
+            }
+        } else {
+            // the DMA of tile t+NSTAGE-1 refills the stage tile t-1 left (all waves passed the barrier): issued piece by piece
+            // between the MFMAs of tile t
+            const bool refill = !(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt;
+            if (refill) {
+                int wr = rd + NSTAGE - 1;
+                if (wr >= NSTAGE) wr -= NSTAGE;
+                tl.issue_begin(lds_base, wr, wave);
+            }
+            constexpr int NM = T::KS * FM * FN;
+            static_assert(T::NPIECE <= NM, "at most one DMA piece per MFMA");
+            // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks (two register sets)
+#if MCRN_BF16_ABL & 2
+            if (t == 0) {
+#else
+            bf16x8_t a[2][FM], b[2][FN];
+            {
+#endif
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[0][i] = *reinterpret_cast<const bf16x8_t*>(sA + aoff[i]);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[0][j] = bf16_read_b<BN, BTR>(sB, boff[j], 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < T::KS; ++ks) {
+                const int cur = (MCRN_BF16_ABL & 2) ? 0 : (ks & 1), nxt = cur ^ 1;
+                if (!(MCRN_BF16_ABL & 2) && ks + 1 < T::KS) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) a[nxt][i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ ((ks + 1) << 5)));
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) b[nxt][j] = bf16_read_b<BN, BTR>(sB, boff[j], ks + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(a[cur][i]), "v"(b[cur][j])); }
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                        const int q = bf16_piece_after((ks * FM + i) * FN + j, NM, T::NPIECE);
+                        if (q >= 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (refill) tl.issue_piece(q, wave);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+            if (refill) tl.issue_end();
         }
         if (++rd == NSTAGE) rd = 0;
     }
@@ -417,7 +517,10 @@ struct PpLoop {
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
         bf16x8_t fa[FM][KS], fb[FN][KS];
+        bool first_load = true;
         auto load_frags = [&](int stg) {
+            if ((MCRN_BF16_ABL & 2) && !first_load) return;
+            first_load = false;
             const unsigned char* sA = smem + stg * T::STAGE;
             const unsigned char* sB = sA + T::ASLOTS * 16;
 #pragma unroll
@@ -428,15 +531,37 @@ struct PpLoop {
                 for (int j = 0; j < FN; ++j) fb[j][ks] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
             }
         };
-        auto compute = [&]() {
+        constexpr int NM = KS * FM * FN;
+        static_assert(T::NPIECE <= NM, "at most one DMA piece per MFMA");
+        // dma_tag: std::true_type = the pieces of the tile opened with issue_begin go between the MFMAs (when `refill`)
+        auto compute = [&](auto dma_tag, bool refill) {
+            if (MCRN_BF16_ABL & 4) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(fa[i][ks]));
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(fb[j][ks]));
+                }
+                return;
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
+                    for (int j = 0; j < FN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                        if constexpr (decltype(dma_tag)::value) {
+                            const int q = bf16_piece_after((ks * FM + i) * FN + j, NM, T::NPIECE);
+                            if (q >= 0) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (refill) tl.issue_piece(q, wave);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
             __builtin_amdgcn_s_setprio(0);
         };
         // wait until this wave's share of tile u has landed: issued so far are tiles <= u + NSTAGE - 2
@@ -454,25 +579,29 @@ struct PpLoop {
         if (grp == 0) {
             for (int t = 0; t < nt; ++t) {
                 load_frags(rd);                                  // phase 2t
-                if (t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                if (!(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                compute();                                       // phase 2t+1
+                compute(std::false_type{}, false);               // phase 2t+1
                 if (t + 1 < nt) wait_landed(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 if (++rd == NSTAGE) rd = 0;
             }
         } else {
-            if (NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }   // phase 0: nothing to compute yet
+            if (!(MCRN_BF16_ABL & 1) && NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }   // phase 0: nothing to compute yet
             __syncthreads();
             for (int t = 0; t < nt; ++t) {
                 load_frags(rd);                                  // phase 2t+1
                 if (t + 1 < nt) wait_landed(t + 1);
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                compute();                                       // phase 2t+2
-                if (t + NSTAGE < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                // phase 2t+2: this group's share of tile t+NSTAGE goes out between its MFMAs (after them, the matrix pipe of
+                // the SIMD sat idle while the wave queued 8 pieces at the address path)
+                const bool refill = !(MCRN_BF16_ABL & 1) && t + NSTAGE < nt;
+                if (refill) tl.issue_begin(lds_base, wr, wave);
+                compute(std::true_type{}, refill);
+                if (refill) { tl.issue_end(); if (++wr == NSTAGE) wr = 0; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nt) __syncthreads();
                 if (++rd == NSTAGE) rd = 0;
@@ -500,7 +629,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     int aoff[L::FM], boff[L::FN];
     bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[L::FM][L::FN];
+    MCRN_CLK_PROBE(0);
     L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
+    MCRN_CLK_PROBE(1);
     if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
         if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128))) return;

@@ -157,6 +157,50 @@ __global__ __launch_bounds__(1024) void k_wunprep(float* __restrict__ dW, const 
     }
 }
 
+// The same reduction with FOUR consecutive outputs per thread (O % 4 == 0: four consecutive reference elements share their
+// (support, k, channel) row, so they are four consecutive slab elements too): 16-byte loads, a wave reads 1 KB of a slab per
+// instruction instead of 256 B - the 256-slab reduction of the N = 1843 decoder gates was running at ~270 GB/s
+// (profiles/r3: 174 us x 4 per step on the helper stream).
+__global__ __launch_bounds__(1024) void k_wunprep4(float* __restrict__ dW, const float* __restrict__ slabs, int nslab,
+                                                   long long slab, int d, int H, int Cp, int K, int O, float* __restrict__ dbias) {
+    __shared__ float4 sh[16][64];
+    const int C = d + H;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + el) * 4;
+    const long long tot = (long long)2 * K * C * O;
+    const long long all = tot + (dbias ? O : 0);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < all) {
+        long long srcoff;
+        if (i < tot) {
+            int o = (int)(i % O);
+            int q = (int)(i / O);
+            int cref = q % C, kg = q / C;
+            int s = kg / K, k = kg % K;
+            int g = (k == 0) ? 0 : 1 + s * (K - 1) + (k - 1);
+            int cp = cref < d ? H + cref : cref - d;
+            srcoff = ((long long)g * Cp + cp) * O + o;
+        } else {
+            const int G = 1 + 2 * (K - 1);
+            srcoff = (long long)G * Cp * O + (i - tot);
+        }
+        const float* src = slabs + srcoff;
+        for (int z = zl; z < nslab; z += 16) {
+            const float4 x = *reinterpret_cast<const float4*>(src + z * slab);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+    }
+    sh[zl][el] = v;
+    __syncthreads();
+    if (zl == 0 && i < all) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int z = 0; z < 16; ++z) { const float4 x = sh[z][el]; t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w; }
+        float* dst = i < tot ? dW + i : dbias + (i - tot);
+        *reinterpret_cast<float4*>(dst) = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // adjacency: g = rowsoftmax(relu(L))  (model/MegaCRN.py:171-172), one wave per row
 // ---------------------------------------------------------------------------------------------

@@ -984,6 +984,7 @@ def test_propagation_harness_matches_float64_reference():
     ({"MCRN_MFORM": "1", "MCRN_PROP1_CT": "4", "MCRN_PROP1_CAP": "16"}, "(model_train_step and metrla) or kernel_variants"),     # 128-column units, several units per workgroup
     ({"MCRN_CELL_BWD_VEC": "0"}, "(model_train_step and (metrla or tiny)) or trainer"),   # scalar forms of the element-wise GRU backward kernels
     ({"MCRN_SIDE2": "0"}, "(model_train_step and (metrla or tiny)) or trainer"),          # decoder weight gradients on the first helper queue (one helper stream)
+    ({"MCRN_WUNPREP_VEC": "0"}, "(model_train_step and (metrla or tiny)) or trainer"),    # one output per thread in the weight-gradient slab reduction (k_wunprep)
     ({"MCRN_TAIL2": "1", "MCRN_WGRAD_DEC_WGS": "256"}, "(model_train_step and (metrla or tiny)) or trainer"),   # encoder gate weight gradient on the second helper queue; full-width decoder weight gradients
     ({"MCRN_AGCN_FUSED": "1"}, "(model_train_step and metrla) or full_size_metrla"),   # one launch per AGCN call (agcn_fused.h, opt-in)
     ({"MCRN_WP_STREAM": "0", "MCRN_BF16_PLANES": "0"}, "(model_train_step and metrla) or (bf16_mode_train and 1843)"),   # tiled weight pool

@@ -113,6 +113,8 @@ int main(int argc, char** argv) {
            btr ? "nn" : "nt", cfg, ns, maxerr, maxref, maxerr / maxref, maxerr_b, rows_checked);
     const bool ok = maxerr / maxref < 2e-5;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (getenv("CB_ONLY") && ns == 1) { p.C = nullptr; p.Cb = dCb; }     // time the bf16-only output form (the model's forward propagation)
+    if (getenv("NO_OUT")) { p.M = 0 * M + M; p.C = nullptr; p.Cb = nullptr; }   // no stores at all (loop + launch cost)
     for (int i = 0; i < 3; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < reps; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
@@ -120,5 +122,13 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * M * N * (double)nseg * seglen;
     printf("  %s  %.2f us/launch  %.1f TFLOP/s\n", ok ? "OK " : "BAD", 1e3 * ms / reps, fl / (ms / reps * 1e-3) / 1e12);
+#if MCRN_BF16_ABL & 8
+    {
+        unsigned long long c[4];
+        CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(mcrn::g_bf16_clk), sizeof c));
+        const double dc = (double)(c[2] - c[0]), dw = (double)(c[3] - c[1]);
+        printf("  clock probe (workgroup 0, K loop): %.0f shader cycles in %.2f us -> %.0f MHz\n", dc, dw / 100.0, dw > 0 ? dc / dw * 100.0 : 0.0);
+    }
+#endif
     return ok ? 0 : 1;
 }
