@@ -59,6 +59,11 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 #ifndef MCRN_BF16_ABL
 #define MCRN_BF16_ABL 0
 #endif
+// where the DMA pieces of a K tile go (A/B builds: make EXTRA=-DMCRN_BF16_ILV=n): bit 1 = between the MFMAs in the ring kernel
+// (wave tiles of 8+ fragments), bit 2 = between the MFMAs of the computing group in the ping-pong kernel; 0 = behind the MFMAs
+#ifndef MCRN_BF16_ILV
+#define MCRN_BF16_ILV 3
+#endif
 #if MCRN_BF16_ABL & 8
 // bit 8: workgroup 0 records the shader-clock counter and the 100 MHz wall clock at both ends of the kernel (the clock the
 // chip really runs at under this load = d(clock64) / d(wall_clock64) x 100 MHz)
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         // Wave tiles of 8+ fragments (128 x 64): the DMA pieces go BETWEEN the MFMAs (see Bf16Tile::issue_piece; -5 .. -8 % per
         // launch).  The 64 x 64 wave tile of the 256 x 128 eight-wave form has only 16 MFMAs per tile for 6 pieces and two
         // waves per SIMD already overlap each other's issue: it keeps the DMA behind its MFMAs (interleaved: +1 %).
-        constexpr bool ILV = FM * FN >= 8;
+        constexpr bool ILV = (MCRN_BF16_ILV & 1) && FM * FN >= 8;
         if constexpr (!ILV) {
 #pragma unroll
             for (int ks = 0; ks < T::KS; ++ks) {
@@ -599,9 +604,14 @@ struct PpLoop {
                 // phase 2t+2: this group's share of tile t+NSTAGE goes out between its MFMAs (after them, the matrix pipe of
                 // the SIMD sat idle while the wave queued 8 pieces at the address path)
                 const bool refill = !(MCRN_BF16_ABL & 1) && t + NSTAGE < nt;
-                if (refill) tl.issue_begin(lds_base, wr, wave);
-                compute(std::true_type{}, refill);
-                if (refill) { tl.issue_end(); if (++wr == NSTAGE) wr = 0; }
+                if constexpr ((MCRN_BF16_ILV & 2) != 0) {
+                    if (refill) tl.issue_begin(lds_base, wr, wave);
+                    compute(std::true_type{}, refill);
+                    if (refill) { tl.issue_end(); if (++wr == NSTAGE) wr = 0; }
+                } else {
+                    compute(std::false_type{}, false);
+                    if (refill) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nt) __syncthreads();
                 if (++rd == NSTAGE) rd = 0;
