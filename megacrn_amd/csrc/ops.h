@@ -370,6 +370,45 @@ __global__ void k_memory_rows(const float* __restrict__ q_rows, const float* __r
     const long long R = (long long)N * B;
     const int wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
     for (long long r = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += (long long)gridDim.x * wpb) {
+        if (M <= 64) {
+            // M <= 64 (every configuration of the reference: mem_num = 20): lane m owns attention weight m - ONE exponential per
+            // lane, the weights travel by lane shuffles (the general form below evaluates 3 M exponentials per lane: 79 us at
+            // N = 1843, compute-bound).  Same expressions, same order of additions: bit-identical outputs.
+            const float scv = lane < M ? sc_rows[r * M + lane] : -3.4e38f;
+            const float mx = wave_max(scv);
+            const float e = lane < M ? expf(scv - mx) : 0.f;
+            float den = wave_sum(e);
+            const float inv = 1.f / den;
+            const float a_own = e * inv;
+            if (lane < M) att_rows[r * M + lane] = a_own;
+            int i0 = 0, i1 = -1; float b0 = -1.f, b1 = -1.f;
+            for (int m = 0; m < M; ++m) {
+                const float a = __shfl(a_own, m);
+                if (a > b0) { b1 = b0; i1 = i0; b0 = a; i0 = m; }
+                else if (a > b1) { b1 = a; i1 = m; }
+            }
+            if (i1 < 0) i1 = i0;
+            const int n = (int)(r / B), b = (int)(r % B);
+            const long long o = ((long long)b * N + n) * D;
+            if (lane == 0) {
+                ind_rows[r * 2] = i0; ind_rows[r * 2 + 1] = i1;
+                if (ind_bnc) { ind_bnc[((long long)b * N + n) * 2] = i0; ind_bnc[((long long)b * N + n) * 2 + 1] = i1; }
+            }
+            for (int d0 = 0; d0 < D; d0 += 64) {                 // (uniform trip count: the shuffles need every lane)
+                const int d = d0 + lane;
+                const int dc = d < D ? d : D - 1;
+                float v = 0.f;
+                for (int m = 0; m < M; ++m) v += __shfl(a_own, m) * Mem[m * D + dc];
+                if (d < D) {
+                    const float qq = q_rows[r * D + d];
+                    val_bnc[o + d] = v; q_bnc[o + d] = qq;
+                    pos_bnc[o + d] = Mem[i0 * D + d]; neg_bnc[o + d] = Mem[i1 * D + d];
+                    if (s0) s0[r * lds0 + H + d] = v;
+                }
+            }
+            if (s0) for (int c = lane; c < H; c += 64) s0[r * lds0 + c] = h[r * ldh + c];
+            continue;
+        }
         // softmax over M (M <= 64 handled in one pass per lane; larger M loops)
         float mx = -3.4e38f;
         for (int m = lane; m < M; m += 64) mx = fmaxf(mx, sc_rows[r * M + m]);
