@@ -1,7 +1,9 @@
 // Stand-alone correctness + timing harness for megacrn_amd/csrc/gemm_bf16.h (no torch).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o bf16_gemm_test bf16_gemm_test.hip
 //   ./bf16_gemm_test probe                      # print the ds_read_b64_tr_b16 lane mapping
-//   ./bf16_gemm_test M N seglen nseg nn|nt cfg nsplit reps
+//   ./bf16_gemm_test M N seglen nseg nn|nt cfg nsplit reps [with_bf16_copy]
+//   env CB_ONLY=1: time the bf16-only output form; NO_OUT=1: time without any store.  Builds with -DMCRN_BF16_ABL=<bits> take one
+//   stream out of the K loop / add the in-kernel clock probe (gemm_bf16.h; profiles/r4/experiments.md section 13).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -114,7 +116,7 @@ int main(int argc, char** argv) {
     const bool ok = maxerr / maxref < 2e-5;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (getenv("CB_ONLY") && ns == 1) { p.C = nullptr; p.Cb = dCb; }     // time the bf16-only output form (the model's forward propagation)
-    if (getenv("NO_OUT")) { p.M = 0 * M + M; p.C = nullptr; p.Cb = nullptr; }   // no stores at all (loop + launch cost)
+    if (getenv("NO_OUT")) { p.C = nullptr; p.Cb = nullptr; }             // no stores at all (K loop + launch cost)
     for (int i = 0; i < 3; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < reps; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
