@@ -32,6 +32,7 @@ CONFIGS = {
 SC_MEAN, SC_STD = 54.4, 19.5
 PEAK = {"f32": 157.3e12, "bf16x3": 2500e12, "bf16": 2500e12}
 HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: HBM3E 8 TB/s   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
+DEFAULT_PREC = {"metrla": "bf16x3", "pemsbay": "bf16x3", "expytky": "bf16", "syn8192": "bf16"}
 ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad", "propagate_inputs"]
 
 
@@ -63,29 +64,62 @@ def alg_flops_forward(cfg, B):
     return float(f)
 
 
-def pmc_traffic(config_name, dtype, N):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
-    (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 per
-    MI355X_MICROARCH.md).  None when no profile of this config is committed."""
-    for rnd in ("r4", "r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", rnd, f"traffic_{config_name}.json")
-        if os.path.exists(path):
-            break
-    else:
+def traffic_profile(config_name, dtype):
+    """The committed PMC traffic table of this config and arithmetic (tools/pmc_traffic.sh, round 5 format): per kernel the
+    FETCH_SIZE x 2 + WRITE_SIZE bytes per launch averaged over the dispatches of ONE steady-state train step (the window
+    between the last two k_clip_adam dispatches of the run: no autotuner candidates, no warm-up), and `_step` = their sum.
+    None when no such profile is committed."""
+    suffix = "" if dtype == DEFAULT_PREC[config_name] else f"_{dtype}"
+    path = os.path.join(ROOT, "profiles", "r5", f"traffic_{config_name}{suffix}.json")
+    if not os.path.exists(path):
         return None
     d = json.load(open(path))
+    return d if "_step" in d else None
+
+
+def pmc_traffic(config_name, dtype, N):
+    """Fabric-side bytes per launch of the dominant kernel (the forward propagation) in a steady-state step:
+    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md."""
+    d = traffic_profile(config_name, dtype)
+    if d is None:
+        return None
     if dtype == "bf16":
         keys = ("true, 1>",)                      # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
-    elif N <= 352 and dtype == "bf16x3":            # matrix-form single-hop kernel (prop_mform.h) / fused two-hop kernels (prop_small.h)
-        keys = ("prop1_kernel",) if mform_on() else ("prop2_fwd_kernel",)
+    elif N <= 352 and dtype == "bf16x3":
+        keys = ("prop2_fwd_kernel",)              # fused two-hop kernels (prop_small.h)
     else:
         keys = ("true, false, 1>",)               # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
     tot = n = 0
     for k, v in d.items():
-        if any(key in k for key in keys) and ("gemm_bf16_" in k or dtype != "bf16"):
+        if k != "_step" and any(key in k for key in keys) and ("gemm_bf16_" in k or dtype != "bf16"):
             tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
+
+
+def step_traffic(config_name, dtype, ms_per_step):
+    """Bytes one steady-state train step moves through the L2s' fabric ports (the sum of the committed PMC table over the step's
+    launches; Infinity-Cache hits are counted, MI355X_MICROARCH.md) and the rate that is at this run's step time."""
+    d = traffic_profile(config_name, dtype)
+    if d is None:
+        return {}
+    gb = d["_step"]["fabric_bytes"] / 1e9
+    return {"step_fabric_gb": round(gb, 3), "step_fabric_tbs": round(gb / ms_per_step, 3),
+            "step_fabric_note": f"sum over the {d['_step']['dispatches']} dispatches of one steady-state step of (2 x FETCH_SIZE + WRITE_SIZE), "
+                                f"collected by tools/pmc_traffic.sh in its own rocprofv3 --pmc runs (profiles/r5/); / this run's ms_per_step"}
+
+
+def small_hoist_fwd(cfg, B):
+    """engine.hip plan_model, Shp::hoist_fwd: the decoder's per-step propagation covers the B*H_dec state columns only where that
+    saves a pass of the fused two-hop kernels (PEMS-BAY at B = 64; not METR-LA, whose full width is one pass of 96-column units)."""
+    env = os.environ.get("MCRN_HOIST_FWD", "1")
+    N, Hd = cfg["N"], cfg["H"] + cfg["D"]
+    if env == "0" or N > 352 or Hd % 64:
+        return False
+    cdiv = lambda a, b: -(-a // b)
+    ld = B * ((Hd + 2 + 3) // 4 * 4)
+    full = 1 if ((N + 31) // 32 <= 8 and cdiv(ld, 96) <= 128) else cdiv(cdiv(ld, 64), 128)
+    return env == "2" or cdiv(B * (Hd // 64), 128) < full
 
 
 def propagation_alg_bytes(cfg, B, dtype):
@@ -100,7 +134,7 @@ def propagation_alg_bytes(cfg, B, dtype):
             out.append(2 * (K - 1) * N * N * 2 + N * B * Hs * 2 + 2 * (K - 1) * N * B * Hs * 2)
         elif dtype == "bf16":     # stacked bf16 adjacency, bf16 input plane, fp32 output planes
             out.append(2 * (K - 1) * N * N * 2 + N * B * C * 2 + 2 * (K - 1) * N * B * C * 4)
-        elif N <= 352 and Hs == H + D and Hs % 64 == 0 and os.environ.get("MCRN_HOIST_FWD", "1") != "0" and not mform_on():
+        elif Hs == H + D and small_hoist_fwd(cfg, B):
             # decoder of the small graphs, forward hoisting (engine.hip Shp::hoist_fwd): the per-step launch covers the state channels
             out.append(2 * N * N * 4 + N * B * Hs * 4 + 2 * (K - 1) * N * B * Hs * 4)
         else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
@@ -205,14 +239,9 @@ def self_launch(args):
     return subprocess.call(launch_cmd(args.gpus, port, sys.argv[1:]), env=launch_env())
 
 
-def mform_on():
-    return os.environ.get("MCRN_MFORM", "0") == "1"     # opt-in (engine.hip plan_model): measured slower at METR-LA
-
-
 def prop_kernel_name(cfg, dtype):
     small = cfg["N"] <= 352 and dtype == "bf16x3"
     return ("mcrn::gemm_bf16(_pp)_kernel<BM,BN,..,BTR=true,ROLE=1> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
-            "mcrn::prop1_kernel<NF,CT,STREAM> (matrix form: [S1; 2 S1 S1 - I; S2; 2 S2 S2 - I] x plane 0, one single-hop launch)" if small and mform_on() else
             "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if small else
             "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
 
@@ -293,7 +322,33 @@ def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
             "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes}
 
 
-def make_trainer(config_name, B, prec, device, rank):
+TILE_DIR = os.path.join(ROOT, "profiles", "tiles")
+
+
+def tile_cache_path(config_name, B, prec):
+    return os.path.join(TILE_DIR, f"{config_name}_B{B}_{prec}.json")
+
+
+def import_tile_cache(config_name, B, prec):
+    """GEMM tile table of this (config, batch, arithmetic) from an earlier mcrn_model_autotune on an MI355X (committed under
+    profiles/tiles/ by `--save-tiles`): with it the one-off tuning of the N = 8192 shape (about a minute) costs nothing, so the SYN
+    leg fits the default run.  Tiles only select among equivalent kernels (speed and fp32 summation order, never results beyond
+    that); a table of another library version is ignored and the shape is tuned as usual."""
+    from megacrn_amd import _lib
+    path = tile_cache_path(config_name, B, prec)
+    if not os.path.exists(path):
+        return False
+    rec = json.load(open(path))
+    if rec.get("lib_version") != _lib.lib.mcrn_version():
+        return False
+    try:
+        _lib.autotune_import(rec["words"])
+    except RuntimeError:
+        return False
+    return True
+
+
+def make_trainer(config_name, B, prec, device, rank, tile_cache=False, save_tiles=None):
     import megacrn_amd
     from megacrn_amd import _lib
     from megacrn_amd.trainer import FlatTrainer
@@ -303,18 +358,27 @@ def make_trainer(config_name, B, prec, device, rank):
     model.precision = _lib.PRECISIONS[prec]
     tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
     batch = synth(cfg, B, 1234 + rank, device)
-    tr._prepare(batch[0])              # workspace + one-off GEMM tile autotune: never inside a timed region
+    tr.tiles_cached = bool(tile_cache) and import_tile_cache(config_name, B, prec)
+    tr._prepare(batch[0])              # workspace + one-off GEMM tile autotune (only signatures the table lacks): never inside a timed region
+    if save_tiles:
+        os.makedirs(os.path.dirname(os.path.abspath(save_tiles)), exist_ok=True)
+        json.dump({"config": config_name, "B": B, "precision": prec, "lib_version": _lib.lib.mcrn_version(),
+                   "words": [int(w) for w in _lib.autotune_export()]}, open(save_tiles, "w"))
     return tr, batch
 
 
-def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True):
-    """The north_star figure, driver-timed: forward N x N propagation at N = 1843 (EXPY-TKY shape, B = 32, T = 6, H = 32)
-    in the bf16-resident arithmetic, as a short extra run after the headline measurement (a few seconds).
-    name = "syn8192" (--with-syn): the same leg on BASELINE configs[4], the N = 8192 roofline run."""
-    prec = "bf16"
+LEG_INDEX = {"expytky": 3, "syn8192": 4}
+
+
+def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True, prec="bf16", nrep=4, tile_cache=False):
+    """The north_star figure, driver-timed: forward N x N propagation at N = 1843 (EXPY-TKY shape, B = 32, T = 6, H = 32) as a
+    short extra run after the headline measurement (a few seconds), in the arithmetic `prec`:
+      bf16   - the bf16-resident large-graph mode (one MFMA per product; stated tolerance 1e-2, tests/test_gpu_parity.py::test_bf16_mode_*)
+      bf16x3 - the parity arithmetic (3 bf16 MFMAs per product, fp32 storage; 1e-4 as north_star states): `secondary_parity`
+    name = "syn8192": the same leg on BASELINE configs[4], the N = 8192 roofline run (tile table from profiles/tiles/)."""
     cfg = CONFIGS[name]
     B = cfg["B"]
-    tr, batch = make_trainer(name, B, prec, device, 0)
+    tr, batch = make_trainer(name, B, prec, device, 0, tile_cache=tile_cache)
     for _ in range(warmup):
         tr.train_step(*batch)
     torch.cuda.synchronize()
@@ -324,13 +388,17 @@ def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     regimes = regime_legs(tr, batch, B, min(steps, 6), 1, torch.cuda.synchronize) if regimes else {}
-    roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=4 if name == "expytky" else 1)
-    return {**regimes, "what": f"forward K-hop propagation at N={cfg['N']} (BASELINE configs[{3 if name == 'expytky' else 4}] shape, per-GPU batch {B}), "
+    roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=nrep)
+    ms = 1e3 * dt / steps
+    tol = {"bf16": "1e-2 (bf16-resident propagation operands; measured <= 5.4e-3)", "bf16x3": "1e-4 (the tolerance north_star states)",
+           "f32": "1e-4"}[prec]
+    return {**regimes, "what": f"forward K-hop propagation at N={cfg['N']} (BASELINE configs[{LEG_INDEX[name]}] shape, per-GPU batch {B}), "
                     "the kernel north_star sets the >= 40 % bf16-MFMA target on; measured in this same process after the headline run",
             "config": {"workload": f"{cfg['label']} N={cfg['N']} T_in=T_out={cfg['T']} rnn_units={cfg['H']} mem={cfg['M']}x{cfg['D']} "
                                    f"cheb_k=3, batch {B}, full train step"},
-            "dtype": prec, "value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 4),
-            "steps": steps, "warmup": warmup, "roofline": roof}
+            "dtype": prec, "parity_tolerance": tol, "value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(ms, 4),
+            "steps": steps, "warmup": warmup, "tile_table_cached": bool(getattr(tr, "tiles_cached", False)),
+            **step_traffic(name, prec, ms), "roofline": roof}
 
 
 def main():
@@ -351,8 +419,12 @@ def main():
                          "(the start of training); the line also carries value_no_teacher (no step teacher-forced) either way")
     ap.add_argument("--no-regimes", action="store_true", help="skip the no-teacher and evaluation-forward legs")
     ap.add_argument("--with-syn", action="store_true",
-                    help="third leg: 3 train steps + forward-propagation roofline of the N = 8192 stress shape (BASELINE configs[4]; "
-                         "~35 GB of workspace, about a minute with its one-off tile autotune: opt-in)")
+                    help="force the third leg (3 train steps + forward-propagation roofline of the N = 8192 stress shape, BASELINE "
+                         "configs[4]; ~35 GB of workspace): by default it runs with 2 steps when profiles/tiles/ holds the tile table of "
+                         "the shape (otherwise its one-off tuning takes about a minute) and 40 GB of HBM are free")
+    ap.add_argument("--no-syn", action="store_true", help="skip the N = 8192 leg of the default run")
+    ap.add_argument("--save-tiles", default=None, help="write the GEMM tile table of this run's shape to PATH after tuning "
+                                                       "(commit it as profiles/tiles/<config>_B<batch>_<precision>.json)")
     ap.add_argument("--roles", default="1,2,3,4,5,6,7", help="GEMM roles timed for gemm_roles (diagnostics); 7 = the hoisted once-per-stack\n                    input-channel products of the bf16 mode (absent in the other modes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -389,7 +461,7 @@ def main():
     # arithmetic: bf16x3 (fp32-equivalent, the 1e-4 parity mode) for the small graphs; the large graphs default to the
     # bf16-resident propagation mode (own stated tolerance, tests/test_gpu_parity.py::test_bf16_mode_*)
     prec = args.precision or ("bf16" if cfg["N"] >= 1024 else "bf16x3")
-    tr, batch = make_trainer(args.config, B, prec, device, rank)
+    tr, batch = make_trainer(args.config, B, prec, device, rank, save_tiles=args.save_tiles if rank == 0 else None)
     x, ycov, y = batch
     dtype = prec
 
@@ -454,7 +526,7 @@ def main():
                                             "frac_of_mfma_peak": round(top[1]["alg_tflops"] * 1e12 / PEAK[dtype], 5)}
         sync_all()
 
-    secondary = None
+    secondary = secondary_parity = None
     if rank == 0 and world == 1 and args.config == "metrla" and not args.no_secondary and not args.no_roofline:
         del tr
         torch.cuda.empty_cache()
@@ -462,14 +534,28 @@ def main():
             secondary = secondary_leg(device)
         except Exception as e:                      # the headline line must not depend on the extra leg
             secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+        try:   # the same shape in the arithmetic that meets north_star's 1e-4 (3 MFMAs per product: its matrix-core ceiling is 833 TF)
+            secondary_parity = secondary_leg(device, steps=4, warmup=1, prec="bf16x3", regimes=False, nrep=1)
+        except Exception as e:
+            secondary_parity = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
 
     tertiary = None
-    if rank == 0 and world == 1 and args.with_syn:
+    # N = 8192 (BASELINE configs[4]): default when the tile table of the shape is committed (no minute of tuning) and 40 GB are free
+    syn_auto = (args.config == "metrla" and not args.no_secondary and not args.no_roofline and not args.no_syn
+                and os.path.exists(tile_cache_path("syn8192", CONFIGS["syn8192"]["B"], "bf16")))
+    if rank == 0 and world == 1 and (args.with_syn or syn_auto):
         torch.cuda.empty_cache()
-        try:
-            tertiary = secondary_leg(device, steps=3, warmup=1, name="syn8192", regimes=False)
-        except Exception as e:
-            tertiary = {"error": f"{type(e).__name__}: {e}"[:300]}
+        free_b = torch.cuda.mem_get_info()[0]
+        if free_b < 40e9 and not args.with_syn:
+            tertiary = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the N = 8192 workspace needs ~35 GB"}
+        else:
+            try:
+                tertiary = secondary_leg(device, steps=2 if not args.with_syn else 3, warmup=1, name="syn8192", regimes=False, nrep=1,
+                                         tile_cache=True)
+            except Exception as e:
+                tertiary = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
 
     cpu = None
@@ -526,8 +612,11 @@ def main():
         if roof:
             out["roofline"] = roof
             out["gemm_roles"] = roles
+        out.update(step_traffic(args.config, dtype, out["ms_per_step"]))
         if secondary:
             out["secondary"] = secondary
+        if secondary_parity:
+            out["secondary_parity"] = secondary_parity
         if tertiary:
             out["syn8192"] = tertiary
         if cpu:

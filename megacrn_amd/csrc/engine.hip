@@ -642,6 +642,16 @@ struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { r
 static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
 // hoisted (the packed operand dPb = [nb][Kp][B*H]): only the state channels of plane 0 receive a propagated gradient here;
 // the input channels' share (needed for the go symbol of a step that was not teacher-forced) is go_grad_bf16 below
+// Round 5: the partial planes of the split product (splits 1 ..) are PACKED bf16 matrices [N*B][H] instead of fp32 planes in the plane-0
+// layout - a 4-way split of the encoder shape wrote 30 MB of fp32 partials per launch against the forward product's 15 MB of bf16
+// output, and the element-wise consumers read them back.  Split 0 still accumulates into plane 0 in fp32; a partial is one bf16
+// rounding (2^-9) of a quarter of the sum, below the rounding the mode's operands already carry.  Hoisted backward only (the packed
+// form has no input channels), with the float4 consumers (k_cell_bwd_b4 / ca4); MCRN_BF16_PARTIALS=0: fp32 partial planes.
+static inline bool propt_partials_bf16(const Shp& s, bool hoisted) {
+    static const bool off = getenv("MCRN_BF16_PARTIALS") && atoi(getenv("MCRN_BF16_PARTIALS")) == 0;
+    static const bool vec_off = getenv("MCRN_CELL_BWD_VEC") && atoi(getenv("MCRN_CELL_BWD_VEC")) == 0;
+    return !off && !vec_off && g_prop_bf16 && hoisted && (s.H & 7) == 0 && (s.Cp & 3) == 0 && (s.PS & 3) == 0;
+}
 static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, int* used_dT, hipStream_t st,
                          bool hoisted = false) {
     Bf16GemmP p = bgp(u);
@@ -658,6 +668,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
         // the extra planes dT .. that the element-wise consumers of plane 0 add in a fixed order (no reduction pass, one
         // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
         p.slab = dT - dP; p.slab2 = s.PS; p.cin_first_only = 1;
+        if (propt_partials_bf16(s, hoisted)) { p.Cpb = reinterpret_cast<uint16_t*>(dT); p.pb_slab = s.R * s.H; p.pb_ld = (int)s.ldh; }
         const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N};
         // (a request the launcher would round to fewer splits - short K: N <= 64 at cheb_k = 3 - is not taken: the consumers
         //  would add partial planes that nothing wrote; 2 is exact for any K of two tiles or more)
@@ -678,7 +689,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
         }
         if (bf16_eff_splits(u.nb, s.N, nsplit) != nsplit) nsplit = 1;          // (a single K tile: nothing to split)
         *used_dT = nsplit - 1;
-        if (nsplit == 1) { p.slab = 0; p.slab2 = 0; p.cin_first_only = 0; }
+        if (nsplit == 1) { p.slab = 0; p.slab2 = 0; p.cin_first_only = 0; p.Cpb = nullptr; }
     }
     return bf16_gemm(p, true, nsplit, ROLE_PROPT, alg, st);
 }
@@ -1375,12 +1386,16 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     const long long dPbS = dPin ? (long long)u.nb * s.PSbh : (long long)u.nb * s.PSb;     // slot of one call
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + dPbS : nullptr, cds, false, dPin, kin,
                       (call0 + 1) * s.B * s.d));
-    if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
-        LAUNCH(k_cell_bwd_b4, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    const bool xbf = propt_partials_bf16(s, dPin != nullptr);      // packed bf16 partial planes behind dTu / dTg (prop_bwd_bf16)
+    if (xbf && !cell_bwd_vec(s, dP, dTu, dTg, dQ, Z, zr, dG, dacc)) FAIL("bf16 partial planes need the float4 GRU-backward kernels (alignment)");
+    if (xbf)
+        LAUNCH(k_cell_bwd_b4<true>, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, RH, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    else if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
+        LAUNCH(k_cell_bwd_b4<false>, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     else
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true, dPin, kin, call0 * s.B * s.d));
-    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, (dPin || s.state_only) ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, xbf ? RH : s.PS, (dPin || s.state_only) ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin, xbf ? 1 : 0);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
     return 0;
@@ -1390,9 +1405,14 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
 static int cell_bwd_ca(const Shp& s, int xcols, const float* dP, const float* dQ, const float* dTu, const float* dTg, int xu, int xg,
                        const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
                        float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
-                       float* dacc, hipStream_t st) {
-    if (cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc))
-        LAUNCH(k_cell_bwd_ca4, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
+                       float* dacc, hipStream_t st, bool xbf = false /* dTu / dTg hold packed bf16 partial planes */) {
+    if (xbf && !cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc)) FAIL("bf16 partial planes need the float4 GRU-backward kernels (alignment)");
+    if (xbf)
+        LAUNCH(k_cell_bwd_ca4<true>, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
+               dTu, xu, s.R * s.H, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
+               Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
+    else if (cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc))
+        LAUNCH(k_cell_bwd_ca4<false>, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
                dTu, xu, s.PS, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
                Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     else
@@ -1845,7 +1865,10 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         static const bool hb_off = getenv("MCRN_HOIST_BWD") && atoi(getenv("MCRN_HOIST_BWD")) == 0;
         static const bool dsw_off = getenv("MCRN_DS_WIDE") && atoi(getenv("MCRN_DS_WIDE")) == 0;
         static const bool dsm_off = getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0;
-        P.sd.hoist_bwd = P.sd.hoist_fwd && !hb_off && !P.defer_ds && ds_small_enabled() && (N <= 256 || !dsw_off) && !dsm_off;
+        // (P.sd.Cp - Hd == 4: the gathered first hop of the hoisted backward - agcn_bwd_core, Prop1P::col0 = H - covers ONE column quad
+        //  per sample; a decoder input wider than 4 channels keeps the full-width backward chain)
+        P.sd.hoist_bwd = P.sd.hoist_fwd && !hb_off && !P.defer_ds && ds_small_enabled() && (N <= 256 || !dsw_off) && !dsm_off &&
+                         (P.sd.Cp - Hd) == 4;
         if (ok || P.sd.hoist_fwd) {
             const long long ce = ok ? (long long)d->T_in * B * (P.se.Cp - H) : 0, cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
             const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 3) & ~3LL) + 4;
@@ -2072,8 +2095,13 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const long long R = se.R;
     // forward hoisting of the decoder's input channels (Shp::hoist_fwd) only pays when steps beyond the first are teacher-forced
     // (evaluation and the late curriculum run every step at full width, with no once-per-stack product)
+    // teacher flags without labels: the forward pass would feed the projection back while the backward pass (which never sees
+    // `labels`) would treat the step as teacher-forced - refused here, so the two passes always agree on every step's go symbol
+    if (teacher && !labels)
+        for (int t = 0; t < To; ++t)
+            if (teacher[t]) FAIL("model_forward: teacher[%d] is set but labels is NULL (model/MegaCRN.py:188-191 needs labels[:, t])", t);
     bool any_teacher = false;
-    for (int t = 0; t + 1 < To; ++t) any_teacher |= teacher && labels && teacher[t];
+    for (int t = 0; t + 1 < To; ++t) any_teacher |= teacher && teacher[t];
     // The step opens with ~40 tiny, mutually independent preparation launches (supports, weight images, input packing:
     // ~0.45 ms of the 6.7 ms METR-LA step, each 5 us of work behind 7 us of launch gap).  Everything that depends on
     // the WEIGHTS and the decoder's inputs only goes to the helper stream and is joined before the first cell.
@@ -2272,7 +2300,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                 CKI(cell_bwd_ca(sd, (bh || prev_hoisted) ? Hd : sd.Cp, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
                                 (long long)To * N * od, (long long)od, use_next, p->proj_w, od, P.dgo + (long long)t * R * od,
                                 P.Zdec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
-                                P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st));
+                                P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st, propt_partials_bf16(sd, bh)));
             }
             CKI(cell_bwd_core(sdt, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
@@ -2390,7 +2418,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
                 CKI(cell_bwd_ca(se, bh ? H : se.Cp, P.dPp[prev], P.dQp[prev], P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
                                 P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
-                                P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
+                                P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st, propt_partials_bf16(se, bh)));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
                               dPt, dQt, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
@@ -2712,7 +2740,10 @@ int mcrn_autotune_import(const int* buf, long long n) {
         }
         i += 2 + nk + 1;
     }
-    g_tuned.swap(a); g_tuned_bf16.swap(b); g_tuned_split.swap(c);
+    // validated as a whole, then merged: entries of other shapes (an earlier leg of the same process) stay
+    for (const auto& kv : a) g_tuned[kv.first] = kv.second;
+    for (const auto& kv : b) g_tuned_bf16[kv.first] = kv.second;
+    for (const auto& kv : c) g_tuned_split[kv.first] = kv.second;
     return 0;
 }
 int mcrn_set_precision(int precision) {

@@ -249,7 +249,7 @@ __device__ __forceinline__ bf16x8_t bf16_read_b(const unsigned char* sB, int bof
 // then stores 16 contiguous bytes: 8 x fewer store instructions, full 128-byte lines.  Only whole-tile fragments, FN == 2.
 template <int FM, int FN>
 __device__ __forceinline__ bool bf16_epilogue_wide(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int r_base, int c_base, int lane,
-                                                   unsigned char* wave_lds) {
+                                                   unsigned char* wave_lds, uint16_t* __restrict__ out, int ldb) {
     if (FN != 2) return false;
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
     if (rw + 32 * FM > p.M || cw + 64 > p.N) return false;                 // wave-uniform
@@ -265,8 +265,7 @@ __device__ __forceinline__ bool bf16_epilogue_wide(const Bf16GemmP& p, f32x16_t 
                 u += 0x7FFFu + ((u >> 16) & 1u);
                 *reinterpret_cast<uint16_t*>(wave_lds + row * 128 + ((64 * j + 2 * l31) ^ (kq << 6))) = (uint16_t)(u >> 16);   // ((row >> 2) & 1) == kq
             }
-    const int ldb = (int)p.cbm.lo;
-    uint16_t* __restrict__ dst = p.Cb + (long long)rw * ldb + cw;
+    uint16_t* __restrict__ dst = out + (long long)rw * ldb + cw;
 #pragma unroll
     for (int n = 0; n < 4 * FM; ++n) {
         const int q = lane + 64 * n, row = q >> 3, c = q & 7;
@@ -281,10 +280,12 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
                                               int lane) {
     const int l31 = lane & 31, kq = lane >> 5;
     const long long soff = p.slab2 > 0 ? (split > 0 ? p.slab + (long long)(split - 1) * p.slab2 : 0) : (long long)split * p.slab;
-    float* __restrict__ C = p.C ? p.C + soff : nullptr;
-    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
+    const bool pb = p.Cpb != nullptr && split > 0;                   // this split's result is a packed bf16 partial plane only
+    float* __restrict__ C = (p.C && !pb) ? p.C + soff : nullptr;
+    const float* __restrict__ Cin = (p.Cin && !pb && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
+    uint16_t* __restrict__ Cbp = pb ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb;
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
-    const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
+    const int ld = (int)p.cm.lo, ldb = pb ? p.pb_ld : (int)p.cbm.lo;
     const bool cols_in = cw + 32 * FN <= p.N;
     // column offset of fragment j (scalar): contiguous columns, or the two-level map of cn_inner / cn_hi - a 32-column
     // fragment never straddles an inner block (cn_inner % 32 == 0, fragments start at multiples of 32)
@@ -302,7 +303,7 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
         const unsigned lo0 = (unsigned)(4 * kq * ld + l31);
         float* __restrict__ Cf = C ? C + base : nullptr;
         const float* __restrict__ Cif = Cin ? Cin + base : nullptr;
-        uint16_t* __restrict__ Cbf = p.Cb ? p.Cb + (long long)rb * ldb + cw : nullptr;
+        uint16_t* __restrict__ Cbf = Cbp ? Cbp + (long long)rb * ldb + cw : nullptr;
         const unsigned lb0 = (unsigned)(4 * kq * ldb + l31);
         if (cols_in && rb + 32 <= p.M) {                             // whole fragment inside: straight-line code
 #pragma unroll
@@ -482,9 +483,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         }
         if (++rd == NSTAGE) rd = 0;
     }
-    if (p.wide_cb && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
+    const bool pbw = p.Cpb != nullptr && split > 0 && p.wide_pb;    // workgroup-uniform (split is)
+    if ((p.wide_cb || pbw) && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
         __syncthreads();                                         // every wave is done reading the operand stages
-        if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128))) return;
+        if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128),
+                                       pbw ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb, pbw ? p.pb_ld : (int)p.cbm.lo)) return;
     }
     bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
@@ -642,9 +645,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     MCRN_CLK_PROBE(0);
     L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
     MCRN_CLK_PROBE(1);
-    if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
+    const bool pbw = p.Cpb != nullptr && split > 0 && p.wide_pb;    // workgroup-uniform (split is)
+    if ((p.wide_cb || pbw) && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
-        if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128))) return;
+        if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128),
+                                             pbw ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb, pbw ? p.pb_ld : (int)p.cbm.lo)) return;
     }
     bf16_epilogue<L::FM, L::FN>(p, acc, split, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
 }
@@ -912,6 +917,7 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
         p.wide_cb = (!wide_off && p.Cb && !p.C && !p.Cin && p.nsplit <= 1 && nsplit <= 1 && (p.cbm.lo & 7) == 0 &&
                      ((uintptr_t)p.Cb & 15) == 0) ? 1 : 0;
     }
+    p.wide_pb = (p.Cpb && (p.pb_ld & 7) == 0 && (p.pb_slab & 7) == 0 && ((uintptr_t)p.Cpb & 15) == 0) ? 1 : 0;
     // each hot role uses one storage form of B; everything else is "misc"
     if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
     if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);

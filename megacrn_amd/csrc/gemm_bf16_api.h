@@ -42,6 +42,10 @@ struct Bf16GemmP {
                               //      whose first slab is the real output and whose further slabs are a separate run of planes
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
+    uint16_t* Cpb;            // split-K with bf16 PARTIAL planes (round 5: the transposed propagation): split 0 takes the fp32 path above
+    long long pb_slab;        // (C / Cin / slab rules unchanged), split z >= 1 writes ONLY a packed bf16 matrix [M][pb_ld] at
+    int pb_ld;                // Cpb + (z - 1) * pb_slab - half the bytes of an fp32 partial plane, full 128-byte lines; the consumers
+    int wide_pb;              // add the partials in a fixed order.  wide_pb: set by the launcher (LDS-staged 16-byte stores possible)
     int xcd;                  // 1: XCD-aware tile order
     int wide_cb;              // set by the launcher: bf16-only output staged through LDS into 16-byte stores
     // stream-K configurations only (launch_gemm_bf16 fills them from the per-stream workspace it owns)

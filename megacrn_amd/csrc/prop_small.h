@@ -850,6 +850,8 @@ __global__ __launch_bounds__(64 * NF) void ds_wide_kernel(const DsP p) {
     };
     fetch(0);
     float* __restrict__ C = (sup == 0 ? p.C[0] : sup == 1 ? p.C[1] : sup == 2 ? p.C[2] : p.C[3]) + (long long)z * p.slab;
+    const int nj = min(NJ, NF - j0);                        // the last column group is ragged (NF = 9, 10, 11 over groups of 4): its
+                                                            // missing fragments are never published and must not be multiplied
     f32x16 acc[NJ];
     {
         const int rows_in = 32 * w + 32 <= p.N;
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(64 * NF) void ds_wide_kernel(const DsP p) {
             const bf16x8 xl = __builtin_bit_cast(bf16x8, img[stg][w][ks][1][pl]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                if (j >= nj) break;                          // block-uniform
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, img[stg][NF + j][ks][0][pl]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, img[stg][NF + j][ks][1][pl]);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);

@@ -142,7 +142,7 @@ def test_supports_and_memory_vs_oracle(amd):
 def build(amd, P, m):
     model = amd.MegaCRN(num_nodes=m["N"], input_dim=1, output_dim=1, horizon=m["T_out"], rnn_units=m["H"],
                         num_layers=m["num_layers"], cheb_k=m["cheb_k"], mem_num=m["M"], mem_dim=m["D"],
-                        cl_decay_steps=m["cl_decay"])
+                        cl_decay_steps=m["cl_decay"], ycov_dim=m.get("ycov_dim", 1))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in P.items()})
     model.precision = amd.test_precision
     return model.cuda()
@@ -371,21 +371,24 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192"),
     (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment"),
     (45, 6, 32, 32, 2, "cheb_k=2: streaming weight pool with 2 propagated planes (wp_stream_kernel<2|4, 2, ..>), fp32 planes"),
+    (48, 6, 32, 32, 3, "ycov_dim=5: decoder input of 6 channels (two column quads beside H_dec = 64); under MCRN_HOIST_FWD=2 the hoisted "
+                       "backward's gathered first hop covers ONE quad, so this width must take the full-width backward chain"),
 ])
 def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
     """Shapes chosen to reach kernel variants the golden cases do not (see `why`): forward and every parameter
     gradient of a train-mode step vs the float64 oracle."""
     M, cheb_k = 4, (2 if why.startswith("cheb_k=2") else 3)
-    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=5)
+    yd = 5 if why.startswith("ycov_dim=5") else 1
+    P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=5, ycov_dim=yd)
     rng = np.random.default_rng(9)
     for k in P:
         if k.endswith("bias"):
             P[k] = (0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
     x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
-    ycov = rng.random((B, T, N, 1)).astype(np.float32)
+    ycov = rng.random((B, T, N, yd)).astype(np.float32)
     y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
-    teacher = [False, True][:T]
-    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000)
+    teacher = [False, True, True][:T]
+    m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000, ycov_dim=yd)
     model = build(amd, P, m).train()
     model._teacher_flags = lambda labels, bs: teacher
     outs = model(dev(x), dev(ycov), dev(y), 0)

@@ -1,34 +1,58 @@
 #!/bin/bash
-# HBM traffic of every kernel of a short bench run: FETCH_SIZE and WRITE_SIZE in separate passes
-# (MI355X_MICROARCH.md: TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2).  usage: tools/pmc_traffic.sh <tag> [bench args]
+# Fabric-side (HBM + Infinity Cache) traffic of ONE steady-state train step, per kernel and in total.
+#   FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (MI355X_MICROARCH.md: TCC has 4 slots, FETCH_SIZE costs 3,
+#   WRITE_SIZE 2; FETCH_SIZE x2 on gfx950 for wide coalesced reads), counters with --kernel-trace only.
+#   Only the dispatches of the LAST train step of the run are kept: the window between the last two k_clip_adam dispatches
+#   (one per optimizer step).  The one-off tile autotune, the warm-up steps and the other legs never enter the table.
+# usage: tools/pmc_traffic.sh <tag> [bench args]      ->  gpurun_out/traffic_<tag>.json  (+ "_step": the sum over the step)
 tag=$1; shift
+set -e
 cd /tmp && export TMPDIR=/tmp
 i=1
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmct_${tag}_$i -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-regimes "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmct_${tag}_$i -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-regimes --no-secondary --no-syn "$@" > /dev/null 2>&1
   i=$((i+1))
 done
 python3 - "$tag" <<'PY'
 import csv, glob, sys, os, collections, re, json
 tag = sys.argv[1]
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
-out = collections.defaultdict(dict); cnt = collections.Counter()
-for i in (1, 2):
-    for f in glob.glob(f"{root}/pmct_{tag}_{i}/**/*counter_collection.csv", recursive=True):
-        acc = collections.defaultdict(list)
+
+
+def step_window(counter):
+    """[(kernel name, value)] of the last train step of one pass, in dispatch order"""
+    rows = []
+    for f in glob.glob(f"{root}/pmct_{tag}_{1 if counter == 'FETCH_SIZE' else 2}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
             n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mcrn::", "").replace("mcrn::", "")
-            acc[(n, r["Counter_Name"])].append(float(r["Counter_Value"]))
-        for (n, c), v in acc.items():
-            out[n][c] = sum(v) / len(v); cnt[n] = len(v)
-res = {}
-for n, d in out.items():
-    f, w = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
+            rows.append((int(r["Dispatch_Id"]), n, float(r["Counter_Value"])))
+    if not rows:
+        sys.exit(f"pmc_traffic: no {counter} rows collected for {tag}")
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if r[1].startswith("k_clip_adam")]
+    if len(marks) < 2:
+        sys.exit(f"pmc_traffic: fewer than two optimizer steps in the {counter} pass of {tag}")
+    return [(n, v) for _, n, v in rows[marks[-2] + 1: marks[-1] + 1]]
+
+
+fetch, write = step_window("FETCH_SIZE"), step_window("WRITE_SIZE")
+if [n for n, _ in fetch] != [n for n, _ in write]:
+    sys.exit(f"pmc_traffic: the two passes of {tag} did not launch the same step ({len(fetch)} vs {len(write)} dispatches)")
+acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for (n, f), (_, w) in zip(fetch, write):
+    a = acc[n]; a[0] += 1; a[1] += f; a[2] += w
+res, total = {}, 0.0
+for n, (k, f, w) in acc.items():
     # units: KiB.  gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (guide, HBM section)
-    res[n] = {"launches": cnt[n], "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
-              "hbm_bytes_per_launch_corrected": (2 * f + w) * 1024}
+    b = (2 * f + w) * 1024 / k
+    res[n] = {"launches": k, "FETCH_SIZE_KiB": f / k, "WRITE_SIZE_KiB": w / k, "hbm_bytes_per_launch_corrected": b}
+    total += b * k
+res["_step"] = {"fabric_bytes": total, "dispatches": len(fetch), "window": "between the last two k_clip_adam dispatches"}
 json.dump(res, open(f"{root}/traffic_{tag}.json", "w"), indent=1, sort_keys=True)
-for n, d in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:12]:
-    print(f"{n[:60]:60s} n={d['launches']:4d} fetch={d['FETCH_SIZE_KiB']/1024:8.2f}MiB write={d['WRITE_SIZE_KiB']/1024:8.2f}MiB")
+print(f"{tag}: one step = {len(fetch)} dispatches, {total / 1e9:.2f} GB through the fabric ports")
+for n, d in sorted(((n, d) for n, d in res.items() if n != "_step"), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:14]:
+    print(f"{n[:60]:60s} n={d['launches']:4d} fetch={d['FETCH_SIZE_KiB']/1024:8.2f}MiB write={d['WRITE_SIZE_KiB']/1024:8.2f}MiB  step share {d['hbm_bytes_per_launch_corrected'] * d['launches'] / total:5.1%}")
 PY
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmct_${tag}_[12]
