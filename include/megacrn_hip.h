@@ -218,7 +218,8 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
 int mcrn_autotune_entries(void);
 int mcrn_autotune_clear(void);
 /* The tile table as a flat int32 record list ({kind, nkey, key words..., cfg} per entry).  export returns the number of
- * words the table needs and fills `buf` when `cap` is large enough (call with NULL/0 first); import REPLACES the table.
+ * words the table needs and fills `buf` when `cap` is large enough (call with NULL/0 first); import validates the whole list, then MERGES it into the table
+ * (entries of other shapes stay; bench.py imports committed tables from profiles/tiles/ that way).
  * Data-parallel ranks tune independently and timing noise may choose different tiles (different fp32 summation
  * orders): rank 0 exports, every other rank imports, so all replicas run identical kernels (megacrn_amd/trainer.py). */
 long long mcrn_autotune_export(int* buf, long long cap);

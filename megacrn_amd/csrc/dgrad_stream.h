@@ -57,8 +57,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
     const int l31 = lane & 31, kq = lane >> 5;
     // workgroup = (group of 4 row fragments, column part); wave w owns row fragment 4*rg + w; the workgroup walks the
     // column fragments of its part together so that every B fragment is fetched from L2 once per 128 rows
-    const int part = (int)(blockIdx.x % p.parts);
-    const long long rg = blockIdx.x / p.parts;
+    // The `parts` workgroups of a row group run on ONE XCD (block b runs on XCD b % 8): they all read the same 128 rows of dY - once
+    // from the memory side, then from that XCD's L2 (round 5: 25 -> 20 us per launch at METR-LA, +3 % on the step; with the parts
+    // dealt round-robin over the XCDs every one of them fetched the rows through the fabric: 79 MB per launch for 25 MB of work).
+    const int xcd = (int)(blockIdx.x & 7);
+    const long long slot = blockIdx.x >> 3;
+    const int part = (int)(slot % p.parts);
+    const long long rg = (slot / p.parts) * 8 + xcd;
+    if (rg * 128 >= p.R) return;                                      // (grid padded to 8 row groups per round; uniform over the workgroup)
     const long long rf = rg * 4 + wave;
     const bool live = rf * 32 < p.R;                                  // whole wave beyond the last row: helps staging only
 #ifdef MCRN_ABLATE
@@ -77,6 +83,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         const long long lim = p.R * O;                                // floats in dY
 #pragma unroll
         for (int h = 0; h < KH; ++h) {
+            {
 #pragma unroll
             for (int i = 0; i < OH / 8; ++i) {                        // 32*OH/4 float4 over 64 lanes
                 const int e = lane + 64 * i;                          // float4 index inside the (32 x OH) block
@@ -86,6 +93,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
                 if (src < 0) src = 0;
                 const float4 x = *reinterpret_cast<const float4*>(p.dY + src);
                 *reinterpret_cast<float4*>(sa + row * AROW + k) = x;
+            }
             }
             // same wave wrote and reads (and overwrites for the next half): LDS operations of a wave complete in order
 #pragma unroll
@@ -219,7 +227,7 @@ static inline hipError_t launch_dgrad_stream(DgradP p, hipStream_t st) {
     if (parts > p.ncf) parts = p.ncf;
     p.cf_per_part = (int)((p.ncf + parts - 1) / parts);
     p.parts = (p.ncf + p.cf_per_part - 1) / p.cf_per_part;
-    dim3 grid((unsigned)(nrg * p.parts));
+    dim3 grid((unsigned)(((nrg + 7) / 8) * 8 * p.parts));             // 8 row groups (one per XCD) per round of `parts` workgroups each
     switch (p.O / 16) {
         case 1: hipLaunchKernelGGL(dgrad_stream_kernel<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(dgrad_stream_kernel<2>, grid, dim3(256), 0, st, p); break;

@@ -32,7 +32,7 @@ using namespace ext;   // host entry points of the kernel units (kernels_api.h)
 
 GemmStats g_gemm_stats = {0, 0.0};
 int g_force_cfg = -1;
-int g_debug = getenv("MCRN_DEBUG") ? atoi(getenv("MCRN_DEBUG")) : 0;   // tuning A/B bits, 0 in production
+int g_debug = 0;                        // ablation bits of the measurement builds (mcrn_set_debug), 0 in production
 static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch (MCRN_F32 or MCRN_BF16X3)
 static bool g_prop_bf16 = false;        // MCRN_BF16: propagation / its transpose / adjacency gradient on bf16-resident operands
                                         // (gemm_bf16.h); every other contraction keeps the bf16x3 arithmetic
@@ -86,7 +86,7 @@ struct CallGuard {
         if (g_device < 0) g_device = dev;
         else if (dev != g_device) {
             snprintf(g_err, sizeof g_err, "libmegacrn_hip: called on device %d after device %d (one device per process: the tile cache, "
-                     "helper stream and stream-K workspaces belong to the first device)", dev, g_device);
+                     "helper stream and tile cache belong to the first device)", dev, g_device);
             return MCRN_EINVAL;
         }
         return 0;
@@ -260,8 +260,7 @@ static int side_guard(int buf, hipStream_t st) {
         g_side.pending[buf] = false;
         // one merged launch read both plane sets of its cell: its completion frees the sibling set as well, and every
         // event wait is a barrier packet of ~6 us in the caller's queue (profiles/r3/experiments.md)
-        static const bool pair_off = getenv("MCRN_PAIR_GUARD") && atoi(getenv("MCRN_PAIR_GUARD")) == 0;
-        if (g_side.paired[buf] && !pair_off) g_side.pending[buf ^ 1] = false;
+        if (g_side.paired[buf]) g_side.pending[buf ^ 1] = false;
     }
     return 0;
 }
@@ -315,8 +314,6 @@ struct Shp {   // one AGCN / cell geometry
     int Kp; long long ldp, PSb;   // MCRN_BF16: bf16 planes are [Kp = roundup(N, 64)][ldp = roundup(ld, 64)], zero padded
     bool hoist; long long ldh;    // MCRN_BF16, H % 32 == 0: the per-step propagation covers the B*H state columns only (ldh);
                                   // the input channels of every step are propagated once per stack
-    bool fused;                   // bf16x3, N <= 256, cheb_k = 3: one launch per AGCN call (agcn_fused.h); the input (and pad)
-                                  // channels of every step are propagated once per stack here too
     long long PSbh;               // Kp * ldh: one packed bf16 [Kp][B*H] matrix
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
@@ -326,8 +323,6 @@ struct Shp {   // one AGCN / cell geometry
                                   // are propagated once per stack (hoist_inputs_small).  state_only: THIS call runs that way.
     bool state_only;
     bool hoist_bwd;               // ... and the backward cells of such steps run their transposed chain on the state columns only
-    bool mform;                   // bf16x3, N <= 352, fused model path: matrix-form Chebyshev terms (prop_mform.h): planes 1 .. nb are
-                                  // single-hop products [S1; 2 S1 S1 - I; S2; 2 S2 S2 - I] x plane 0, the d-grad weights are not folded
 };
 static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     Shp s;
@@ -341,15 +336,11 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.PS = s.R * s.Cp;
     s.ZT = s.PS * s.G;
     s.Kp = (N + 63) & ~63; s.ldp = (s.ld + 63) & ~63LL; s.PSb = (long long)s.Kp * s.ldp;
-    static const bool hoist_off = getenv("MCRN_HOIST") && atoi(getenv("MCRN_HOIST")) == 0;
-    s.hoist = bf16_rows && !hoist_off && (H % 32) == 0 && d > 0;
+    s.hoist = bf16_rows && (H % 32) == 0 && d > 0;
     s.ldh = (long long)B * H;
     s.PSbh = (long long)s.Kp * s.ldh;
-    s.fused = false;              // (set by plan_model: needs both output widths of the cell and the session precision)
-    s.mform = false;              // (set by plan_model)
     s.hoist_fwd = false; s.state_only = false; s.hoist_bwd = false;
-    static const bool lite_off = getenv("MCRN_BF16_PLANES") && atoi(getenv("MCRN_BF16_PLANES")) == 0;
-    s.lite = s.hoist && !lite_off && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
+    s.lite = s.hoist && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
 }
 
@@ -366,26 +357,26 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     int nslab;
     long long slab;
     long long sup_stride;   // floats between the slab sets of support 0 and 1
-    bool defer;     // adjacency gradient is computed once per stack by ds_deferred_kernel
+    bool ds4 = false;   // fused model path, cheb_k = 3 (round 5): the adjacency gradient is four blocks [d1_a, e2_a, d1_b, e2_b] x x0^T over the
+                        // RAW d-grad planes (dS then holds 4 blocks per slab: [nslab][4][N*ldS], slab = 4*N*ldS), the chain rule of 2 S S runs
+                        // once per step (model_backward), and the transposed chain never writes d1t back
     // MCRN_BF16 (gemm_bf16.h): stacked bf16 adjacency [S1; T2(S1); S2; T2(S2)] (rows padded to Kp) and its transpose
     const uint16_t* Sstk = nullptr;
     const uint16_t* STstk = nullptr;
     int Kp = 0, nb = 0;
     float *mu = nullptr, *mu_part = nullptr;    // column sums of a plane over its nodes (+ partials)
-    // matrix form of the small graphs (prop_mform.h): fragment images of [S1, 2 S1 S1, S2, 2 S2 S2] and of their transposes;
-    // dS then holds nbm output blocks per slab ([nslab][nbm][N*ldS], slab = nbm*N*ldS)
-    bool mform = false;
-    int nbm = 0;
-    const uint4* Mf[4] = {nullptr, nullptr, nullptr, nullptr};
-    const uint4* Mtf[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 static int nslab_S(int N) {
     // N <= 256: one ds_small workgroup per slab; its slab read + write is ~9 us whatever its K range, so fewer,
     // fatter workgroups cost less GPU time (measured METR-LA: 16 -> 7070, 24 -> 8090, 32 -> 8260, 48 -> 8150, 64 -> 8060 samples/s)
-    static const int env = getenv("MCRN_NSLAB_S") ? atoi(getenv("MCRN_NSLAB_S")) : 0;
-    static const int wide = getenv("MCRN_NSLAB_W") ? atoi(getenv("MCRN_NSLAB_W")) : 32;     // 256 < N <= 512 (ds_wide_kernel at N <= 352)
-    const int small = env > 0 ? env : 32;
-    return N <= 256 ? small : N <= 512 ? wide : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
+    // (256 < N <= 512, ds_wide_kernel at N <= 352: 12 -> 5 783, 16 -> 6 210, 24 -> 6 381, 32 -> 6 383, 48 -> 6 221 samples/s at PEMS-BAY)
+    return N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
+}
+// four-block form (Sup::ds4): 4 x nslab workgroups per launch, each with one K segment per call instead of two
+static int nslab_S4(int N) {
+    static const int env = getenv("MCRN_NSLAB_S4") ? atoi(getenv("MCRN_NSLAB_S4")) : 0;     // TEMPORARY sweep knob (round 5)
+    (void)N;
+    return env > 0 ? env : 16;
 }
 static const int NSLAB_W = 256;   // slab capacity of the deferred weight gradients (reduced by k_wunprep)
 static const int NSLAB_W_GEMM = 64;   // ... slabs the tiled-GEMM fallback splits K into
@@ -393,19 +384,13 @@ static const int NSLAB_T = 256;   // split-K slabs of the tiny-output, very-long
 static const int NSLAB_E = 16;    // split-K slabs of dE1 / dE2 (N x D outputs, K = N)
 
 static const int MCRN_MAX_CHEB_K = 8;     // model/MegaCRN.py:21-22 recurses for any cheb_k >= 2; 2 and 3 have the fused fast paths
-static inline bool ds_small_enabled() {
-    static const bool on = !(getenv("MCRN_DS_SMALL") && atoi(getenv("MCRN_DS_SMALL")) == 0);   // default on: 9.9 vs 10.7 ms/step at METR-LA
-    return on;
-}
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool use_prop_small(const Sup& u, const Shp& s) {
     return g_precision == MCRN_BF16X3 && s.K <= 3 && u.Sf[0] && u.Stf[0] && prop_small_ok(s.N, s.ld, (int)s.ld);
 }
 // fused two-hop kernels (cheb_k = 3): also 256 < N <= 352, where the other adjacency-stationary kernels do not reach
 static inline bool use_prop2(const Sup& u, const Shp& s) {
-    static const bool wide_off = getenv("MCRN_PROP2_WIDE") && atoi(getenv("MCRN_PROP2_WIDE")) == 0;
-    return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && s.K == 3 && prop2_ok(s.N, s.ld, (int)s.ld) &&
-           !(wide_off && s.N > 256);
+    return g_precision == MCRN_BF16X3 && u.Sf[0] && u.Stf[0] && s.K == 3 && prop2_ok(s.N, s.ld, (int)s.ld);
 }
 
 static GemmP gp() {
@@ -499,7 +484,7 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
         } else cfg = bf16_cfg_prior(p, nsplit);
     }
     const bool prof = g_prof.role == (prof_role >= 0 ? prof_role : role) && g_prof.n < Prof::MAXEV;
-    const bool ext = prof && !bf16_cfg_is_sk(cfg);          // events attached to the dispatch (the stream-K launcher records around it)
+    const bool ext = prof;                                  // events attached to the dispatch
     if (ext) { p.ev0 = g_prof.ev[2 * g_prof.n]; p.ev1 = g_prof.ev[2 * g_prof.n + 1]; }
     else if (prof) CK(hipEventRecord(g_prof.ev[2 * g_prof.n], st));
     CK(launch_gemm_bf16(p, btr, cfg, nsplit, role, st));
@@ -603,21 +588,21 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
            s.ZT, s.PS, s.ld, s.Cp, col0);
     return 0;
 }
-// Small graphs with the fused AGCN kernel: the same hoisting in fp32 / bf16x3.  Columns [col0, col0 + w) of plane 0 of T plane
+// Small graphs (Shp::hoist_fwd): the same hoisting in fp32 / bf16x3.  Columns [col0, col0 + w) of plane 0 of T plane
 // sets are packed into an N x (T*B*w) matrix, propagated by the fused two-hop kernel (planes 1 .. 4 of the scratch set) and
 // scattered into planes 1 .. 4 of Z[t] and Y[t].  The pad channels ride along (w reaches Cp): S x 0 = 0 is what the
-// unfused propagation wrote there, and the adjacency gradient reads those columns.
+// full-width propagation writes there, and the adjacency gradient reads those columns.
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b, uint16_t* x0c, uint16_t* Pb, bool packed);
 static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, int T, int col0, int w, float* xin_f, hipStream_t st) {
-    if (!(s.fused || s.hoist_fwd) || w <= 0 || T <= 0) return 0;
+    if (!s.hoist_fwd || w <= 0 || T <= 0) return 0;
     const int ncols = T * s.B * w;
     const int ncp = (ncols + 3) & ~3;
     const long long tot0 = (long long)s.N * ncp;
     LAUNCH(k_pack_cols_f32, dim3(cdiv(tot0, 256)), dim3(256), 0, st, (const float*)Z, s.ZT, s.N, s.ld, s.Cp, col0, w, s.B, T, ncp, xin_f);
     Shp t = s;
-    t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.fused = false; t.hoist_fwd = false; t.state_only = false;
+    t.ld = ncp; t.PS = (long long)s.N * ncp; t.hoist = false; t.lite = false; t.hoist_fwd = false; t.state_only = false;
     Prop2P q;
-    q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
+    q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.no_d1 = 0;
     q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
     const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
     MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
@@ -642,16 +627,9 @@ struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { r
 static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
 // hoisted (the packed operand dPb = [nb][Kp][B*H]): only the state channels of plane 0 receive a propagated gradient here;
 // the input channels' share (needed for the go symbol of a step that was not teacher-forced) is go_grad_bf16 below
-// Round 5: the partial planes of the split product (splits 1 ..) are PACKED bf16 matrices [N*B][H] instead of fp32 planes in the plane-0
-// layout - a 4-way split of the encoder shape wrote 30 MB of fp32 partials per launch against the forward product's 15 MB of bf16
-// output, and the element-wise consumers read them back.  Split 0 still accumulates into plane 0 in fp32; a partial is one bf16
-// rounding (2^-9) of a quarter of the sum, below the rounding the mode's operands already carry.  Hoisted backward only (the packed
-// form has no input channels), with the float4 consumers (k_cell_bwd_b4 / ca4); MCRN_BF16_PARTIALS=0: fp32 partial planes.
-static inline bool propt_partials_bf16(const Shp& s, bool hoisted) {
-    static const bool off = getenv("MCRN_BF16_PARTIALS") && atoi(getenv("MCRN_BF16_PARTIALS")) == 0;
-    static const bool vec_off = getenv("MCRN_CELL_BWD_VEC") && atoi(getenv("MCRN_CELL_BWD_VEC")) == 0;
-    return !off && !vec_off && g_prop_bf16 && hoisted && (s.H & 7) == 0 && (s.Cp & 3) == 0 && (s.PS & 3) == 0;
-}
+// (Round 5 measured bf16 / packed partial planes behind this split product: the read-modify-write epilogue of split 0 is what makes it
+//  slower than the forward product - 52 vs 45 us without it - but every byte-saving form rounds the partial sums to bf16 and costs the
+//  mode 25 % of its accuracy and its batch additivity; the exact fp32 form below stays.  profiles/r5/experiments.md section 2.)
 static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* dPb, float* dT, int* used_dT, hipStream_t st,
                          bool hoisted = false) {
     Bf16GemmP p = bgp(u);
@@ -661,14 +639,13 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
     if (hoisted) { p.ldb = s.ldh; p.N = (int)s.ldh; p.b_seg = s.PSbh; p.cn_inner = s.H; p.cn_hi = s.Cp; }
     int nsplit = 1;
-    static const int split_env = getenv("MCRN_BF16_PROPT_SPLIT") ? atoi(getenv("MCRN_BF16_PROPT_SPLIT")) : 0;   // 0: tuned (2 .. 4)
+    const int split_env = 0;                                 // K splits: tuned (2 .. 4) with the tile
     const double alg = (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * (hoisted ? s.H : s.C);
     if (dT && used_dT && split_env != 1 && !bf16_cfg_is_sk(g_force_cfg_bf16) && (long long)cdiv(s.N, 128) * cdiv(p.N, 128) < 512) {
         // The output is only N x B*Cp while K is nb*N deep: K is split, split 0 accumulates into plane 0, the others land in
         // the extra planes dT .. that the element-wise consumers of plane 0 add in a fixed order (no reduction pass, one
         // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
         p.slab = dT - dP; p.slab2 = s.PS; p.cin_first_only = 1;
-        if (propt_partials_bf16(s, hoisted)) { p.Cpb = reinterpret_cast<uint16_t*>(dT); p.pb_slab = s.R * s.H; p.pb_ld = (int)s.ldh; }
         const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N};
         // (a request the launcher would round to fewer splits - short K: N <= 64 at cheb_k = 3 - is not taken: the consumers
         //  would add partial planes that nothing wrote; 2 is exact for any K of two tiles or more)
@@ -689,7 +666,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
         }
         if (bf16_eff_splits(u.nb, s.N, nsplit) != nsplit) nsplit = 1;          // (a single K tile: nothing to split)
         *used_dT = nsplit - 1;
-        if (nsplit == 1) { p.slab = 0; p.slab2 = 0; p.cin_first_only = 0; p.Cpb = nullptr; }
+        if (nsplit == 1) { p.slab = 0; p.slab2 = 0; p.cin_first_only = 0; }
     }
     return bf16_gemm(p, true, nsplit, ROLE_PROPT, alg, st);
 }
@@ -757,71 +734,14 @@ static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long l
     return 0;
 }
 
-// ---- matrix-form single-hop propagation of the small graphs (prop_mform.h) -------------------------------------------
-struct Prop1Cfg { int ct, stream, cap, bwd_ny; };
-static const Prop1Cfg& prop1_cfg() {
-    static const Prop1Cfg c = {
-        getenv("MCRN_PROP1_CT") ? atoi(getenv("MCRN_PROP1_CT")) : 2,
-        getenv("MCRN_PROP1_STREAM") ? atoi(getenv("MCRN_PROP1_STREAM")) : 1,
-        getenv("MCRN_PROP1_CAP") ? atoi(getenv("MCRN_PROP1_CAP")) : 0,
-        getenv("MCRN_PROP1_BWD_NY") ? atoi(getenv("MCRN_PROP1_BWD_NY")) : 0 /* 0: one group per block */};
-    return c;
-}
-static int prop1_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st) {
-    if (!aligned16(Z)) FAIL("matrix-form propagation: plane set not 16-byte aligned");
-    Prop1P q;
-    memset(&q, 0, sizeof q);
-    const int nb = u.nbm;
-    for (int k = 0; k < nb; ++k) {
-        q.Sf[k] = u.Mf[k]; q.src[k] = Z; q.out[k] = Z + (long long)(1 + k) * s.PS;
-        if (s.K == 3 && (k & 1)) { q.add0[k] = Z; q.coef0[k] = -1.f; }          // T2 x = (2 S S) x - x
-    }
-    q.ny = nb; q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld;
-    const Prop1Cfg& c = prop1_cfg();
-    const double alg = nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, ex = nb * 2.0 * (double)s.N * s.N * (double)s.ld;
-    MCRN_PROF_WRAP_EXT(ROLE_PROP, q, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
-    return 0;
-}
-// backward: dP[0] += sum_k A_k^T dP[1 + k] (- dP[2] - dP[4]: the "- I" of the T2 blocks); the nb blocks are dealt to ny groups,
-// group 0 accumulates into plane 0, group y > 0 stores its partial into the extra plane dT + (y - 1) * PS that the
-// element-wise consumers of plane 0 add (one writer per element, fixed order)
-static int prop1_bwd(const Shp& s, const Sup& u, float* dP, float* dT, int* used_dT, hipStream_t st) {
-    if (!aligned16(dP) || !dT) FAIL("matrix-form propagation: gradient planes not aligned / no partial planes");
-    Prop1P q;
-    memset(&q, 0, sizeof q);
-    const int nb = u.nbm;
-    const Prop1Cfg& c = prop1_cfg();
-    int ny = c.bwd_ny > 0 ? c.bwd_ny : nb;
-    if (ny > nb || nb % ny || nb / ny > 2 || ny - 1 > PROPT_MAX_X) ny = nb;
-    const int nseg = nb / ny;
-    for (int k = 0; k < nb; ++k) { q.Sf[k] = u.Mtf[k]; q.src[k] = dP + (long long)(1 + k) * s.PS; }
-    for (int y = 0; y < ny; ++y) {
-        q.out[y] = y == 0 ? dP : dT + (long long)(y - 1) * s.PS;
-        int na = 0;
-        auto push = [&](const float* a, float cf) { if (na == 0) { q.add0[y] = a; q.coef0[y] = cf; } else { q.add1[y] = a; q.coef1[y] = cf; } ++na; };
-        if (y == 0) push(dP, 1.f);
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int k = y * nseg + sg;
-            if (s.K == 3 && (k & 1)) push(dP + (long long)(1 + k) * s.PS, -1.f);
-        }
-        if (na > 2) FAIL("matrix-form propagation: more than two addends in one group");
-    }
-    q.ny = ny; q.nseg = nseg; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld;
-    if (used_dT) *used_dT = ny - 1;
-    const double alg = nb * 2.0 * (double)s.N * s.N * (double)s.B * s.C, ex = nb * 2.0 * (double)s.N * s.N * (double)s.ld;
-    MCRN_PROF_WRAP(ROLE_PROPT, launch_prop1(q, c.ct, c.stream != 0, c.cap, st), ex, alg);
-    return 0;
-}
-
 // ---- K-hop propagation, forward:  planes[1..] from plane 0   (model/MegaCRN.py:19-25) --------
 static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16_t* x0b = nullptr, uint16_t* x0c = nullptr,
                     uint16_t* Pb = nullptr, bool packed = false) {
     if (g_prop_bf16 && u.Sstk && x0b) return prop_fwd_bf16(s, u, Z, x0b, x0c, st, Pb, packed);
-    if (s.mform) return prop1_fwd(s, u, Z, st);
     if (use_prop2(u, s) && aligned16(Z)) {   // both hops, one launch
         Prop2P q;
         q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = Z; q.extra = nullptr; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
-        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.no_d1 = 0;
         double alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;   // 2 hops x 2 supports
         double ex = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.ld;
         if (s.state_only) {          // the input / pad channels of this step's planes were propagated once per stack
@@ -935,6 +855,11 @@ static int agcn_bwd_general(const Shp& s, const Sup& u, const float* dY, int O, 
     return 0;
 }
 
+// the d-grad of this call runs on the streaming kernel (dgrad_stream.h; imgd is then the B-fragment image of Wd, built by wprep
+// under the same test)
+static inline bool dgrad_streams(const Shp& s, int O, const float* dY, const uint4* imgd) {
+    return s.K <= 3 && imgd && g_precision == MCRN_BF16X3 && dgrad_stream_ok(O) && aligned16(dY);
+}
 // ---- AGCN backward core: dY (R x O) -> dP planes; plane 0 of dP ends as d(input); dS slabs += ----
 static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, const float* Wd,
                          const float* X, float* dP, hipStream_t st, int buf = 0, const uint4* imgd = nullptr,
@@ -946,9 +871,10 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     bool dgrad_wrote_bf16 = false;
     const bool side = g_use_side && !g_tuning && g_prof.role < 0;   // tuning / profiling time kernels in-line
     if (side) { CKI(side_init()); CKI(side_guard(buf, st)); }
-    if (imgd && g_precision == MCRN_BF16X3 && dgrad_stream_ok(O) && aligned16(dY)) {
+    if (dgrad_streams(s, O, dY, imgd)) {
         // d-grad, streaming form (dgrad_stream.h): imgd is the B-fragment image of Wd (built by wprep under the same test)
         DgradP q;
+        memset(&q, 0, sizeof q);
         q.dY = dY; q.Wfrag = imgd; q.dP = dP; q.R = s.R; q.PS = s.PS; q.O = O; q.ncols = s.G * s.Cp; q.Cp = s.Cp; q.dbg = g_debug;
         q.dPb = nullptr; q.PSb = 0; q.H = 0; q.d = s.d; q.B = s.B; q.dPin = nullptr; q.kin = 0; q.in_plane = 0; q.in_col0 = 0;
         if (g_prop_bf16 && u.STstk && dPb && dPin) {            // hoisted backward: packed state channels + the input operand
@@ -983,27 +909,24 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st);
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
-    const bool fused_bwd = !s.mform && use_prop2(u, s) && aligned16(dP) && dT != nullptr;
-    if (s.mform) {
-        // matrix form: the whole transposed propagation is ONE single-hop launch over the nb blocks (prop_mform.h)
-        CKI(prop1_bwd(s, u, dP, dT, used_dT, st));
-    } else if (fused_bwd) {
+    const bool fused_bwd = use_prop2(u, s) && aligned16(dP) && dT != nullptr;
+    if (fused_bwd) {
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
         Prop2P q;
-        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.Mf[0] = q.Mf[1] = nullptr;
+        q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.no_d1 = u.ds4 ? 1 : 0;
         q.Sf[0] = u.Stf[0]; q.Sf[1] = u.Stf[1]; q.base = dP; q.extra = dT; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.ncols = (int)s.ld;
         if (used_dT) *used_dT = 1;
         double ex = 4.0 * 2.0 * (double)s.N * s.N * (double)s.ld, alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
         if (s.state_only) {
             // hoisted backward (small graphs): the chain runs on the B*H state columns only - nothing consumes the propagated gradient
-            // of this cell's input channels (its go symbol was known in advance) - and the first hop on the input / pad channels,
-            // d1 += S^T e2, which the adjacency gradient still reads, is a gathered single-hop launch in front of that gradient
+            // of this cell's input channels (its go symbol was known in advance), and the adjacency gradient reads the raw d-grad
+            // planes on every column (Sup::ds4; rounds 4's gathered first hop on the input channels is gone with d1t)
             q.cps = s.H / 64; q.nunits = s.B * q.cps; q.cstride = s.Cp;
             ex = alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
         }
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, alg);
-    } else if (s.K == 3 && small) {   // (not reached in the matrix form: its branch is the first of this chain)
+    } else if (s.K == 3 && small) {
         PropP q;
         memset(&q, 0, sizeof q);
         q.nseg = 1; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.alpha = 1.f; q.beta = 1.f;
@@ -1030,30 +953,28 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     }
     // 256 < N <= 352 (PEMS-BAY): the output-stationary kernel with column groups (ds_wide_kernel) behind the fused two-hop
     // chain, merged per cell like the N <= 256 one, instead of one tiled split-K GEMM per call (MCRN_DS_WIDE=0)
-    static const bool ds_wide_off = getenv("MCRN_DS_WIDE") && atoi(getenv("MCRN_DS_WIDE")) == 0;
-    const bool wide_ds = !ds_wide_off && s.N > 256 && s.N <= PROP2_MAX_N && (s.mform || fused_bwd) && (s.ld % 4) == 0;
-    const bool ds_small_path = !u.defer && (s.mform ? (s.N <= 256 || wide_ds) : (small || wide_ds)) && aligned16(X) && ds_small_enabled();
+    const bool wide_ds = s.N > 256 && s.N <= PROP2_MAX_N && fused_bwd && (s.ld % 4) == 0;
+    const bool ds_small_path = (small || wide_ds) && aligned16(X);
     if (cell_ds && cell_ds->nseg > 0 && !ds_small_path)
         // the update call of this cell queued its d1t x0^T / e2 x1^T segments for a merged launch; the gate call must
         // take the same branch, or those contributions to dS would be silently dropped
         FAIL("adjacency gradient: the two AGCN calls of a cell chose different paths (%d segments queued)", cell_ds->nseg);
-    if (s.state_only && !s.mform && !ds_small_path)
-        FAIL("hoisted backward: the adjacency gradient of this call does not run through ds_small / ds_wide (the gathered first hop lives there)");
-    if (u.defer) {
-        // nothing here: d1t / e2 stay in this call's plane set and are consumed by the deferred launch
-    } else if (ds_small_path) {   // output-stationary adjacency-gradient kernel (prop_small.h)
+    if (u.ds4 && !(fused_bwd && ds_small_path && s.K == 3))
+        FAIL("adjacency gradient: the four-block form was planned but this call does not run the fused two-hop chain + ds_small / ds_wide");
+    if (ds_small_path) {   // output-stationary adjacency-gradient kernel (prop_small.h)
         // The two AGCN calls of a cell (update first, gate second) share ONE launch: every workgroup adds both calls'
         // products to its slab partial while it sits in the accumulators, so the slab is read and written once per cell
         // instead of once per call (the slab read-modify-write was ~1/3 of this kernel's HBM bytes, profiles/r1).
         DsP q_local;
         DsP& q = cell_ds ? *cell_ds : q_local;
         if (!cell_ds || cell_ds->nseg == 0) memset(&q, 0, sizeof q);
-        const int s0 = q.nseg, own = s.mform ? 1 : (s.K == 3 ? 2 : 1);
-        const int nblk = s.mform ? u.nbm : 2;
+        const int s0 = q.nseg, own = u.ds4 ? 1 : (s.K == 3 ? 2 : 1);
+        const int nblk = u.ds4 ? 4 : 2;
         q.nseg = s0 + own; q.N = s.N; q.ncols = (int)s.ld; q.ld = s.ld; q.ldc = u.ldS; q.slab = u.slab;
-        if (s.mform) {
-            // matrix form: dA_k = dP_k x0^T - plane 0 is the only right operand, one segment per call and block
-            for (int k = 0; k < nblk; ++k) {
+        if (u.ds4) {
+            // four blocks over the RAW d-grad planes, plane 0 of the call's input the only right operand:
+            //   dA[2b] += d1_b x0^T ; dA[2b + 1] += e2_b x0^T      (dS_b = dA[2b] + dA[2b+1] S_b^T + S_b^T dA[2b+1]: model_backward)
+            for (int k = 0; k < 4; ++k) {
                 q.A[k][s0] = dP + (long long)(1 + k) * s.PS; q.B[k][s0] = X;
                 q.C[k] = u.dS + (long long)k * s.N * u.ldS;
             }
@@ -1072,27 +993,8 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                 CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
                 ds_st = g_side.st;
             }
-            if (s.state_only && !s.mform) {
-                // first hop of the transposed chain on the input / pad channels of every call of this launch (16 samples' quads
-                // per unit, one group per (call, support)):  d1[:, in] += S^T e2[:, in]
-                Prop1P g;
-                memset(&g, 0, sizeof g);
-                const int ncall = q.nseg / 2;
-                for (int c = 0; c < ncall; ++c)
-                    for (int b = 0; b < 2; ++b) {
-                        const int y = 2 * c + b;
-                        g.Sf[y] = u.Stf[b]; g.src[y] = q.A[b][2 * c + 1];
-                        g.out[y] = const_cast<float*>(q.A[b][2 * c]); g.add0[y] = q.A[b][2 * c]; g.coef0[y] = 1.f;
-                    }
-                g.ny = 2 * ncall; g.nseg = 1; g.N = s.N; g.ncols = (int)s.ld; g.ld = s.ld;
-                g.cstep = s.Cp; g.col0 = s.H; g.nunits = cdiv(s.B, 16);
-                ++g_launches;
-                CK(launch_prop1(g, 2, false, 0, ds_st));
-            }
             {
                 hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
-                static const bool dbg_skip = getenv("MCRN_DBG_SKIP_DS") != nullptr;   // timing experiments only (wrong gradients)
-                if (!dbg_skip)
                 MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st, nblk), ex, nblk * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
             }
             if (side) {
@@ -1105,34 +1007,6 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
                 }
                 g_side.any = true;
             }
-        }
-    } else if (s.mform) {
-        // matrix form on the tiled GEMM (256 < N <= 352): dA_k += dP_k x0^T, two blocks per launch, split-K into slabs
-        hipStream_t ds_st = st;
-        if (side) {
-            CK(hipEventRecord(g_side.ready[buf], st));
-            CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
-            ds_st = g_side.st;
-        }
-        for (int k0 = 0; k0 < u.nbm; k0 += 2) {
-            GemmP p = gp();
-            p.M = s.N; p.N = s.N; p.K = (int)s.ld;
-            p.am = plain(s.ld); p.ak = plain(1);
-            p.bn = plain(s.ld); p.bk = plain(1);
-            p.cm = plain(u.ldS); p.cn = plain(1);
-            p.nbatch = 2; p.beta = 1.f; p.slab = u.slab;
-            for (int b = 0; b < 2; ++b) {
-                p.A[b] = dP + (long long)(1 + k0 + b) * s.PS;
-                p.B[b] = X;
-                p.C[b] = u.dS + (long long)(k0 + b) * s.N * u.ldS;
-                p.Cin[b] = p.C[b];
-            }
-            p.alg_flops = 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.C;
-            CKI(gemm(p, true, true, u.nslab, ROLE_DS, ds_st));
-        }
-        if (side) {
-            CK(hipEventRecord(g_side.done[buf], g_side.st));
-            g_side.pending[buf] = true; g_side.paired[buf] = false; g_side.any = true;
         }
     } else
     {   // dS_s += d1t x0^T (+ e2 x1^T)      N x N, K = (1|2) * B*Cp, split-K into slabs
@@ -1160,7 +1034,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             CKI(gemm(p, true, true, u.nslab, ROLE_DS, st));
         }
     }
-    if (fused_bwd || s.mform) {
+    if (fused_bwd) {
         // done above
     } else if (small) {   // dx0 = dP[0] + S1^T d1t_a + S2^T d1t_b : two K-segments into one accumulator
         PropP q;
@@ -1199,9 +1073,8 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
 // The streaming kernel (wgrad_stream.h) takes every shape of the library's bf16x3 sessions; exact-fp32 sessions and odd
 // widths keep the tiled GEMM.  Returns the number of slabs written through *nslab.
 static bool wgrad_streams(const Shp& s, int O, const float* Xall, const float* dYall, long long step_stride, int T) {
-    static const bool off = getenv("MCRN_WGRAD_STREAM") && atoi(getenv("MCRN_WGRAD_STREAM")) == 0;
     // T > NSLAB_W (one slab per step at least): the tiled split-K GEMM has no such limit
-    return !off && T <= NSLAB_W && g_precision == MCRN_BF16X3 && wgrad_stream_ok(s.G, s.Cp, O) && aligned16(Xall) && aligned16(dYall) &&
+    return T <= NSLAB_W && g_precision == MCRN_BF16X3 && wgrad_stream_ok(s.G, s.Cp, O) && aligned16(Xall) && aligned16(dYall) &&
            ((step_stride | s.PS) & 3) == 0;
 }
 static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, int T, const float* dYall,
@@ -1281,19 +1154,6 @@ static int centre_planes(const Shp& s, const Sup& u, const float* Zall, const fl
 }
 
 // ---- cell forward / backward cores (model/MegaCRN.py:38-48) ----------------------------------------
-// one AGCN call as one launch (agcn_fused.h): propagation of both supports + weight pool + GRU epilogue
-static int agcn_fused(const Shp& s, const Sup& u, float* Z, const uint4* img, const float* bias, int epi, float* out, float* out2,
-                      long long out2_ld, const float* hsrc, long long hsrc_ld, const float* zr, hipStream_t st) {
-    AgcnFP q;
-    memset(&q, 0, sizeof q);
-    q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.Z = Z; q.PS = s.PS; q.ld = s.ld; q.N = s.N; q.B = s.B; q.H = s.H; q.d = s.d; q.Cp = s.Cp;
-    q.O = epi == AGF_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
-    q.out = out; q.out2 = out2; q.out2_ld = out2_ld; q.hsrc = hsrc; q.hsrc_ld = hsrc_ld; q.zr = zr;
-    const double prop = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;              // 2 hops x 2 supports, state channels
-    const double wp = 2.0 * (double)s.R * (2.0 * s.K * s.C) * q.O;
-    MCRN_PROF_WRAP(ROLE_PROP, launch_agcn_fused(q, st), prop * (q.O / 64) + wp, prop + wp);
-    return 0;
-}
 struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if_g = nullptr, *id_g = nullptr, *if_u = nullptr, *id_u = nullptr;
                const uint4 *wp_g = nullptr, *wp_u = nullptr; /* weight images of the streaming weight pool (wp_stream.h) */ };
 // streaming weight pool on bf16-resident planes (wp_stream.h) with the library's profiling hooks
@@ -1326,14 +1186,7 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
         CKI(wp_stream(s, u, Y, Pb + PbS, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, x0b_next, Z, s.Cp, zr, st, xc));
         return 0;
     }
-    static const int fused_maxh = getenv("MCRN_AGCN_FUSED_MAXH") ? atoi(getenv("MCRN_AGCN_FUSED_MAXH")) : 1 << 30;   // A/B: fuse cells up to this width only
-    if (s.fused && s.H <= fused_maxh && w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && !g_prop_bf16 && u.Sf[0] && aligned16(Z) && aligned16(Y)) {
-        CKI(agcn_fused(s, u, Z, w.wp_g, w.bg, AGF_GATE, zr, Y, s.Cp, nullptr, 0, nullptr, st));
-        CKI(agcn_fused(s, u, Y, w.wp_u, w.bu, AGF_UPDATE, hc, hnext, hnext_ld, Z, s.Cp, zr, st));
-        return 0;
-    }
-    static const int wp_dbg = getenv("MCRN_WP_DBG") ? atoi(getenv("MCRN_WP_DBG")) : 3;   // debugging: bit 0 = H <= 64 cells, bit 1 = H > 64 cells
-    if (w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && aligned16(Z) && aligned16(Y) && (wp_dbg & (s.H <= 64 ? 1 : 2))) {
+    if (w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && aligned16(Z) && aligned16(Y)) {
         // streaming weight pool on fp32 planes (bf16x3 arithmetic: the 1e-4 parity mode of the small graphs)
         CKI(prop_fwd(s, u, Z, st, x0b, x0c));
         CKI(wp_stream(s, u, Z, nullptr, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, nullptr, nullptr, 0, nullptr, st));
@@ -1358,8 +1211,7 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
 // and the plane stride PS are multiples of 4 floats by construction)
 template <class... Ps>
 static inline bool cell_bwd_vec(const Shp& s, Ps... ptrs) {
-    static const bool off = getenv("MCRN_CELL_BWD_VEC") && atoi(getenv("MCRN_CELL_BWD_VEC")) == 0;
-    if (off || (s.H & 3) || (s.Cp & 3) || (s.PS & 3)) return false;
+    if ((s.H & 3) || (s.Cp & 3) || (s.PS & 3)) return false;
     const void* a[] = {ptrs...};
     for (const void* p : a) if (p && !aligned16(p)) return false;
     return true;
@@ -1381,21 +1233,18 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     // MCRN_DS_MERGE=0: one launch per call).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the
     // merged launch holds both sets and the main queue waited for it); cells now alternate between two pairs
     // (7.29 vs 7.39 ms).
-    static const bool merge_ds = !(getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0);
-    DsP* cds = merge_ds ? &cell_ds : nullptr;
+    DsP* cds = &cell_ds;
     const long long dPbS = dPin ? (long long)u.nb * s.PSbh : (long long)u.nb * s.PSb;     // slot of one call
     CKI(agcn_bwd_core(s, u, dU, s.H, w.Wd_u, Y, dP, st, 2 * pair, w.id_u, dTu, &xu, dPb ? dPb + dPbS : nullptr, cds, false, dPin, kin,
                       (call0 + 1) * s.B * s.d));
-    const bool xbf = propt_partials_bf16(s, dPin != nullptr);      // packed bf16 partial planes behind dTu / dTg (prop_bwd_bf16)
-    if (xbf && !cell_bwd_vec(s, dP, dTu, dTg, dQ, Z, zr, dG, dacc)) FAIL("bf16 partial planes need the float4 GRU-backward kernels (alignment)");
-    if (xbf)
-        LAUNCH(k_cell_bwd_b4<true>, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, RH, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
-    else if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
-        LAUNCH(k_cell_bwd_b4<false>, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
+    // (Step B was also built INTO the loader of the gate call's streaming d-grad - one launch less per cell - and measured neutral:
+    //  the kernel's 7 us of loads move into the d-grad's serial prologue, six times over; profiles/r5/experiments.md section 5.)
+    if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
+        LAUNCH(k_cell_bwd_b4, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     else
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     CKI(agcn_bwd_core(s, u, dG, 2 * s.H, w.Wd_g, Z, dQ, st, 2 * pair + 1, w.id_g, dTg, &xg, dPb, cds, true, dPin, kin, call0 * s.B * s.d));
-    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, xbf ? RH : s.PS, (dPin || s.state_only) ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin, xbf ? 1 : 0);
+    if (do_c) LAUNCH(k_cell_bwd_c, dim3(cdiv(s.R * s.C, 256)), dim3(256), 0, st, (const float*)dQ, (const float*)dTg, xg, (const float*)dP, (const float*)dTu, xu, s.PS, (dPin || s.state_only) ? s.H : s.Cp, (long long)s.Cp, s.H, s.d, s.R, dacc, dxin);
     if (xu_out) *xu_out = xu;
     if (xg_out) *xg_out = xg;
     return 0;
@@ -1405,14 +1254,9 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
 static int cell_bwd_ca(const Shp& s, int xcols, const float* dP, const float* dQ, const float* dTu, const float* dTg, int xu, int xg,
                        const float* dout_bt, long long out_sb, long long out_sn, int use_next, const float* Wp, int od,
                        float* dgo_rows, const float* Z, const float* zr, const float* hc, float* dU, float* dG,
-                       float* dacc, hipStream_t st, bool xbf = false /* dTu / dTg hold packed bf16 partial planes */) {
-    if (xbf && !cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc)) FAIL("bf16 partial planes need the float4 GRU-backward kernels (alignment)");
-    if (xbf)
-        LAUNCH(k_cell_bwd_ca4<true>, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
-               dTu, xu, s.R * s.H, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
-               Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
-    else if (cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc))
-        LAUNCH(k_cell_bwd_ca4<false>, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
+                       float* dacc, hipStream_t st) {
+    if (cell_bwd_vec(s, dQ, dTg, dP, dTu, Z, zr, hc, dU, dG, dacc))
+        LAUNCH(k_cell_bwd_ca4, dim3(cdiv(s.R * s.H / 4, 256)), dim3(256), 0, st, dQ, dTg, xg, dP,
                dTu, xu, s.PS, xcols, (long long)s.Cp, dout_bt, out_sb, out_sn, use_next, Wp, od, dgo_rows, s.B,
                Z, (long long)s.Cp, zr, hc, s.H, s.R, dU, dG, dacc);
     else
@@ -1435,9 +1279,8 @@ static int relu_softmax_rows_bwd(const float* L, long long ldl, const float* G, 
     return 0;
 }
 // ---- supports (model/MegaCRN.py:169-172) ----------------------------------------------------------
-struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n;
-                 float* M2[2]; uint4* mfrag[8]; /* matrix form: 2 S S per support, images of [S1, M2_1, S2, M2_2] (cheb_k = 2: [S1, S2]) + transposes */ };
-static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o, int mform_K = 0) {
+struct SupBufs { float *E1, *E2, *L1, *L2, *g1, *g2, *St1, *St2, *dLa, *dLb, *dLs, *dE1, *dE2, *dE_s; long long ldS; uint4* frag[4]; uint4* simg[4]; int simg_n; };
+static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o) {
     size_t nn = (size_t)N * ldS, nd = (size_t)N * D;
     o.ldS = ldS;
     o.E1 = b.take<float>(nd); o.E2 = b.take<float>(nd);
@@ -1450,8 +1293,6 @@ static void plan_sup(Bump& b, int N, int M, int D, long long ldS, SupBufs& o, in
     for (int i = 0; i < 4; ++i) o.frag[i] = N <= PROP2_MAX_N ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
     o.simg_n = (N + 3) & ~3;
     for (int i = 0; i < 4; ++i) o.simg[i] = N > 256 ? b.take<uint4>(bimg_uint4(N, N)) : nullptr;
-    for (int i = 0; i < 2; ++i) o.M2[i] = mform_K == 3 ? b.take<float>(nn) : nullptr;
-    for (int i = 0; i < 8; ++i) o.mfrag[i] = mform_K ? b.take<uint4>(sfrag_uint4(N)) : nullptr;
 }
 static int transpose(float* dst, long long ldd, const float* src, long long lds_, const float* add,
                      long long lda, int N, hipStream_t st) {
@@ -1475,7 +1316,7 @@ struct ExactFp32 {
     ~ExactFp32() { g_precision = saved; }
 };
 static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2, const float* Mem,
-                        const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st, int mform_K = 0) {
+                        const SupBufs& o, float* g1, long long ldg, float* g2, bool want_T, hipStream_t st) {
     // The logits go through relu: a logit within the bf16x3 error (1e-5) of zero would get the wrong SIGN and flip
     // its mask in the backward pass (one whole row of dWe1 / dWe2 off by 1e-2: tests/test_gpu_parity.py, H = 8,
     // mem_num = 4).  These three GEMMs are tiny and run once per step, so they are evaluated in exact fp32, like
@@ -1505,33 +1346,8 @@ static int sup_fwd_core(int N, int M, int D, const float* We1, const float* We2,
     if (want_T) {
         CKI(transpose(o.St1, o.ldS, g1, ldg, nullptr, 0, N, st));
         CKI(transpose(o.St2, o.ldS, g2, ldg, nullptr, 0, N, st));
-        if (mform_K) {
-            // matrix form (prop_mform.h): M2_s = 2 S_s S_s once per step in exact fp32 (model/MegaCRN.py:20-22 builds the same
-            // matrix on every AGCN call), then the fragment images of every block and of its transpose in ONE launch
-            if (ldg != o.ldS) FAIL("matrix form: supports must share the workspace row stride");
-            const int nb = 2 * (mform_K - 1);
-            if (mform_K == 3) {
-                ExactFp32 exact_m2;
-                GemmP p = gp();
-                p.M = N; p.N = N; p.K = N; p.nbatch = 2; p.alpha = 2.f;
-                p.am = plain(ldg); p.ak = plain(1);
-                p.bk = plain(ldg); p.bn = plain(1);
-                p.cm = plain(o.ldS); p.cn = plain(1);
-                for (int b = 0; b < 2; ++b) { p.A[b] = b ? g2 : g1; p.B[b] = b ? g2 : g1; p.C[b] = o.M2[b]; p.Cin[b] = nullptr; }
-                CKI(gemm(p, true, false, 0, ROLE_MISC, st));
-            }
-            const float* src[8]; int tr[8];
-            for (int k = 0; k < nb; ++k) {
-                const int sidx = k / (mform_K - 1), t2 = mform_K == 3 && (k & 1);
-                src[k] = t2 ? o.M2[sidx] : (sidx ? g2 : g1); tr[k] = 0;
-                src[nb + k] = src[k]; tr[nb + k] = 1;
-            }
-            uint4* dst[8];
-            for (int k = 0; k < nb; ++k) { dst[k] = o.mfrag[k]; dst[nb + k] = o.mfrag[4 + k]; }
-            ++g_launches; CK(launch_sfrag_multi(src, tr, dst, 2 * nb, ldg, N, st));
-        } else
         CKI(build_frags(g1, g2, ldg, N, o.frag, st));
-        if (!mform_K && o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
+        if (o.simg[0] && g_precision == MCRN_BF16X3) {   // A[m][k] images: element(k, n=m) = S[m*ld + k]
             const float* src[4] = {g1, g2, o.St1, o.St2};
             const long long lds_[4] = {ldg, ldg, o.ldS, o.ldS};
             for (int i = 0; i < 4; ++i) { ++g_launches; CK(launch_bimg_build(src[i], 1LL, lds_[i], N, N, o.simg_n, 1, o.simg[i], st)); }
@@ -1608,7 +1424,7 @@ static int zero_cols(float* dst, long long dst_t, int Cp, int c0, int c1, long l
 static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipStream_t st, uint4* imgf = nullptr,
                  uint4* imgd = nullptr) {
     long long tot = (long long)s.G * s.Cp * O;
-    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, (g_prop_bf16 || s.mform || s.K != 3) ? 0 : 1);
+    LAUNCH(k_wprep, dim3(cdiv(tot, 256)), dim3(256), 0, st, W, Wf, Wd, s.d, s.H, s.Cp, s.K, O, (g_prop_bf16 || s.K != 3) ? 0 : 1);
     if (imgf && g_precision == MCRN_BF16X3) {
         const int Kp = s.G * s.Cp;
         {   // weight pool: B[k = k'][n = o] = Wf[k'*O + o]
@@ -1629,9 +1445,8 @@ static int wprep(const float* W, float* Wf, float* Wd, const Shp& s, int O, hipS
 static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream_t st, int nslab, float* dbias = nullptr) {
     long long tot = (long long)2 * s.K * s.C * O + (dbias ? O : 0);
     const long long slab = (long long)(s.G * s.Cp + (dbias ? 1 : 0)) * O;
-    static const bool vec_off = getenv("MCRN_WUNPREP_VEC") && atoi(getenv("MCRN_WUNPREP_VEC")) == 0;
     // four outputs per thread when every 4-group stays inside one row of both layouts and every address is 16-byte aligned
-    if (!vec_off && (O & 3) == 0 && (slab & 3) == 0 && (((uintptr_t)dW | (uintptr_t)slabs | (uintptr_t)dbias) & 15) == 0) {
+    if ((O & 3) == 0 && (slab & 3) == 0 && (((uintptr_t)dW | (uintptr_t)slabs | (uintptr_t)dbias) & 15) == 0) {
         LAUNCH(k_wunprep4, dim3(cdiv(tot, 256)), dim3(1024), 0, st, dW, slabs, nslab, slab, s.d, s.H, s.Cp, s.K, O, dbias);
         return 0;
     }
@@ -1647,7 +1462,8 @@ struct ModelPlan {
     long long ldS;
     int nslabS;
     SupBufs sup;
-    float *dS;                               // [2][nslabS][N*ldS]
+    float *dS;                               // [2][nslabS][N*ldS]   (ds4: [nslabS][4][N*ldS])
+    bool ds4; float* dAm;                    // four-block adjacency gradient of the fused small-graph path (Sup::ds4), its reduced blocks
     float *Wf[4], *Wd[4], *dWs[4];           // enc gate, enc update, dec gate, dec update
     uint4 *imgf[4], *imgd[4];                // their pre-split tile images (weight pool / d-grad B operands)
     float *Zenc, *Yenc, *zr_e, *hc_e;
@@ -1658,11 +1474,6 @@ struct ModelPlan {
     // adjacency-gradient launch may lag NPAIR - 1 cells behind the main stream before the main stream has to wait
     static const int NPAIR = 3;
     float *dPp[NPAIR], *dQp[NPAIR];
-    float *dPall_e, *dPall_d;      // deferred adjacency gradient: gradient planes of every AGCN backward call
-    float *dSdef; int ndef_e, ndef_d;   // its slabs: [2 supports][ndef_d + ndef_e][N*ldS]
-    bool defer_ds;
-    bool mform;                       // matrix-form Chebyshev terms on the small graphs (prop_mform.h)
-    float* dAm;                       // ... the reduced adjacency-gradient blocks [nb][N*ldS]
     float *dU_e, *dG_e, *dU_d, *dG_d;
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
@@ -1679,7 +1490,7 @@ struct ModelPlan {
     float *Xp_e, *Xp_d;              // compact propagated input channels of the stacks, [T][nb][R][4] (d <= 4; k_scatter_compact)
     bool bwd_hoist; long long kin_e, kin_d;
     uint16_t *dPin_e, *dPin_d, *xin_c; float* go_tmp;
-    float* xin_f;                    // small graphs, fused AGCN kernel: scratch plane set [5][N][ncp] of the hoisted input channels
+    float* xin_f;                    // small graphs, Shp::hoist_fwd: scratch plane set [5][N][ncp] of the hoisted input channels
     uint16_t *Pb_e, *Pb_d;           // bf16-resident propagated planes of every AGCN call: [T][gate, update][nb][N][B*H]
     uint4* wpimg[4];                 // weight images of the streaming weight pool (enc gate, enc update, dec gate, dec update)
     size_t total;
@@ -1706,29 +1517,13 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.sd = mk_shape(B, N, od + yd, Hd, K, P.bf16);
     P.ldS = d->precision == MCRN_BF16 ? (N + 7) & ~7 : (N + 3) & ~3;
     P.nslabS = nslab_S(N);
-    P.defer_ds = false; P.ndef_d = P.ndef_e = 0;
-    {
-        // experimental (measured slower at METR-LA: the long deferred launch starves the critical path): opt-in
-        static const bool defer_env = getenv("MCRN_DEFER_DS") && atoi(getenv("MCRN_DEFER_DS")) == 1;
-        P.defer_ds = defer_env && K <= 3 && N <= 256 && d->precision == MCRN_BF16X3 && (P.sd.ld % 4) == 0;
-        if (P.defer_ds) P.ndef_d = ds_deferred_chunks((int)P.sd.ld);
-    }
-    {
-        // matrix-form Chebyshev terms (prop_mform.h) for the bf16x3 sessions on graphs of N <= 352: every AGCN call is one
-        // single-hop product over nb independent row blocks instead of the fused two-hop feature recursion.  OPT-IN
-        // (MCRN_MFORM=1), parity-tested: measured SLOWER at METR-LA (9 500 vs 10 560 samples/s, profiles/r4/experiments.md):
-        // twice the workgroups each load the full 200 KB fragment image of their block for ONE hop instead of two, and 272 /
-        // 528 workgroups of 7 waves are two rounds on 256 CUs where the fused kernel runs one.
-        static const bool mform_on = getenv("MCRN_MFORM") && atoi(getenv("MCRN_MFORM")) == 1;
-        static const bool fused_on = getenv("MCRN_AGCN_FUSED") && atoi(getenv("MCRN_AGCN_FUSED")) == 1;
-        P.mform = mform_on && !fused_on && !P.defer_ds && d->precision == MCRN_BF16X3 && K <= 3 &&
-                  prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
-        P.se.mform = P.sd.mform = P.mform;
-    }
-    plan_sup(b, N, M, D, P.ldS, P.sup, P.mform ? K : 0);
-    const int nblkS = P.mform ? 2 * (K - 1) : 2;                           // output blocks of the adjacency gradient
-    P.dS = b.take<float>((size_t)nblkS * (P.nslabS + P.ndef_d) * N * P.ldS);   // per support: [per-call split-K slabs | decoder deferred slabs]
-    P.dAm = P.mform ? b.take<float>((size_t)nblkS * N * P.ldS) : nullptr;
+    plan_sup(b, N, M, D, P.ldS, P.sup);
+    // four-block adjacency gradient (Sup::ds4) wherever the fused two-hop chain and the output-stationary kernels take both cell shapes
+    static const bool ds4_off = getenv("MCRN_DS4") && atoi(getenv("MCRN_DS4")) == 0;        // TEMPORARY A/B knob (round 5)
+    P.ds4 = !ds4_off && d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
+    if (P.ds4) P.nslabS = nslab_S4(N);
+    P.dS = b.take<float>((size_t)(P.ds4 ? 4 : 2) * P.nslabS * N * P.ldS);   // split-K slabs of the adjacency gradient (per support / per block)
+    P.dAm = P.ds4 ? b.take<float>((size_t)4 * N * P.ldS) : nullptr;         // ... the four reduced blocks
     const Shp* sh[4] = {&P.se, &P.se, &P.sd, &P.sd};
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) {
@@ -1761,8 +1556,6 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         P.dTu = b.take<float>(pmax * PROPT_MAX_X);        // extra partial planes of plane 0 (K splits 1 .. 3 / second support)
         P.dTg = b.take<float>(pmax * PROPT_MAX_X);
     }
-    P.dPall_e = P.dSdef = nullptr;
-    P.dPall_d = P.defer_ds ? b.take<float>((size_t)d->T_out * 2 * P.sd.ZT) : nullptr;
     P.dU_e = b.take<float>((size_t)d->T_in * R * H);
     P.dG_e = b.take<float>((size_t)d->T_in * R * 2 * H);
     P.dU_d = b.take<float>((size_t)d->T_out * R * Hd);
@@ -1795,14 +1588,12 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         if (P.se.lite && P.sd.lite) {
             P.Pb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * N * P.se.ldh + 64);     // (+ slack: 16-byte reads of 8-byte quads)
             P.Pb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * N * P.sd.ldh + 64);
-            static const bool xp_off = getenv("MCRN_BF16_COMPACT_IN") && atoi(getenv("MCRN_BF16_COMPACT_IN")) == 0;
-            if (!xp_off && d->input_dim <= 4 && od + yd <= 4) {
+            if (d->input_dim <= 4 && od + yd <= 4) {
                 P.Xp_e = b.take<float>((size_t)d->T_in * P.nb * R * 4 + 64);
                 P.Xp_d = b.take<float>((size_t)d->T_out * P.nb * R * 4 + 64);
             }
-            static const bool bh_off = getenv("MCRN_BF16_BWD_HOIST") && atoi(getenv("MCRN_BF16_BWD_HOIST")) == 0;
             const int bwe = B * d->input_dim, bwd_ = B * (od + yd);
-            P.bwd_hoist = !bh_off && (bwe % 8) == 0 && (bwd_ % 8) == 0;
+            P.bwd_hoist = (bwe % 8) == 0 && (bwd_ % 8) == 0;
             if (P.bwd_hoist) {
                 P.kin_e = ((long long)2 * d->T_in * bwe + 63) & ~63LL;
                 P.kin_d = ((long long)2 * d->T_out * bwd_ + 63) & ~63LL;
@@ -1836,21 +1627,9 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     }
     P.xin_f = nullptr;
     {
-        // one launch per AGCN call (agcn_fused.h): bf16x3 sessions on graphs whose adjacency fits a wave's registers
-        // OPT-IN (MCRN_AGCN_FUSED=1): measured SLOWER at METR-LA (profiles/r3/README.md): a workgroup has to run both supports
-        // (and both 64-channel chunks of the decoder state) one after the other, and each is the same serial chain
-        // stage -> hop -> image -> hop that the unfused kernel runs on twice as many workgroups in parallel: 51 us for an
-        // encoder call against 15 + 17 us for the unfused pair.  Kept parity-tested (test_alternative_paths_keep_parity).
-        static const bool fused_on = getenv("MCRN_AGCN_FUSED") && atoi(getenv("MCRN_AGCN_FUSED")) == 1;
-        const bool ok = fused_on && d->precision == MCRN_BF16X3 && K == 3 && N <= 256 &&
-                        agcn_fused_ok(N, H, d->input_dim, H, P.se.ld, P.se.Cp) && agcn_fused_ok(N, H, d->input_dim, 2 * H, P.se.ld, P.se.Cp) &&
-                        agcn_fused_ok(N, Hd, od + yd, Hd, P.sd.ld, P.sd.Cp) && agcn_fused_ok(N, Hd, od + yd, 2 * Hd, P.sd.ld, P.sd.Cp) &&
-                        wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(Hd, od + yd, P.nb, Hd);
-        P.se.fused = P.sd.fused = ok;
         // forward hoisting of the decoder's input channels on the fused two-hop path (see Shp::hoist_fwd); the encoder gains nothing
         // from it (4352 and 4096 columns are both one round of 128 - 136 workgroups: profiles/r4/experiments.md)
         static const bool hf_off = getenv("MCRN_HOIST_FWD") && atoi(getenv("MCRN_HOIST_FWD")) == 0;
-        static const bool p2w_off = getenv("MCRN_PROP2_WIDE") && atoi(getenv("MCRN_PROP2_WIDE")) == 0;      // (use_prop2)
         // ... where it saves a PASS of the fused kernels: the wide variant (N > 256: 64-column units only) walks the decoder's
         // 132 units of PEMS-BAY in two passes of 66 workgroups per support and its 128 state-only units in one (54.6 -> 29 us
         // forward, 65.5 -> 31 us backward in tools/kbench/prop1_test).  At N <= 256 the full width already fits one pass of
@@ -1860,25 +1639,18 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
         static const int hf_env = getenv("MCRN_HOIST_FWD") ? atoi(getenv("MCRN_HOIST_FWD")) : 1;
         const int NFp = (N + 31) / 32, u2f = cdiv(P.sd.ld, 64), u3f = cdiv(P.sd.ld, 96), ust = B * (Hd / 64);
         const int passes_full = (NFp <= 8 && u3f <= 128) ? 1 : cdiv(u2f, 128), passes_state = cdiv(ust > 0 ? ust : 1, 128);
-        P.sd.hoist_fwd = !hf_off && !ok && !P.mform && d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.sd.ld, (int)P.sd.ld) &&
-                         !(p2w_off && N > 256) && (Hd % 64) == 0 && P.sd.Cp > Hd && (passes_state < passes_full || hf_env == 2);
-        static const bool hb_off = getenv("MCRN_HOIST_BWD") && atoi(getenv("MCRN_HOIST_BWD")) == 0;
-        static const bool dsw_off = getenv("MCRN_DS_WIDE") && atoi(getenv("MCRN_DS_WIDE")) == 0;
-        static const bool dsm_off = getenv("MCRN_DS_MERGE") && atoi(getenv("MCRN_DS_MERGE")) == 0;
-        // (P.sd.Cp - Hd == 4: the gathered first hop of the hoisted backward - agcn_bwd_core, Prop1P::col0 = H - covers ONE column quad
-        //  per sample; a decoder input wider than 4 channels keeps the full-width backward chain)
-        P.sd.hoist_bwd = P.sd.hoist_fwd && !hb_off && !P.defer_ds && ds_small_enabled() && (N <= 256 || !dsw_off) && !dsm_off &&
-                         (P.sd.Cp - Hd) == 4;
-        if (ok || P.sd.hoist_fwd) {
-            const long long ce = ok ? (long long)d->T_in * B * (P.se.Cp - H) : 0, cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
-            const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 3) & ~3LL) + 4;
+        P.sd.hoist_fwd = !hf_off && d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.sd.ld, (int)P.sd.ld) &&
+                         (Hd % 64) == 0 && P.sd.Cp > Hd && (passes_state < passes_full || hf_env == 2);
+        P.sd.hoist_bwd = P.sd.hoist_fwd;
+        if (P.sd.hoist_fwd) {
+            const long long cd = (long long)d->T_out * B * (P.sd.Cp - Hd);
+            const size_t ncp = (size_t)((cd + 3) & ~3LL) + 4;
             P.xin_f = b.take<float>((size_t)5 * N * ncp);
         }
     }
     {
         // streaming weight pool (wp_stream.h): bf16x3 sessions (fp32 planes) and the bf16 mode (bf16-resident planes when lite)
-        static const bool wp_off = getenv("MCRN_WP_STREAM") && atoi(getenv("MCRN_WP_STREAM")) == 0;
-        const bool ok = !wp_off && d->precision != MCRN_F32 && wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(H, d->input_dim, P.nb, 2 * H) &&
+        const bool ok = d->precision != MCRN_F32 && wp_stream_ok(H, d->input_dim, P.nb, H) && wp_stream_ok(H, d->input_dim, P.nb, 2 * H) &&
                         wp_stream_ok(Hd, od + yd, P.nb, Hd) && wp_stream_ok(Hd, od + yd, P.nb, 2 * Hd);
         if (ok)
             for (int i = 0; i < 4; ++i) P.wpimg[i] = b.take<uint4>(wp_img_uint4(i < 2 ? H : Hd, P.nb, Os[i]));
@@ -1895,24 +1667,17 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.simg_n = P.sup.simg_n;
     u.ldS = P.ldS;
     u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * P.ldS;
-    u.sup_stride = (long long)(P.nslabS + P.ndef_d) * u.slab;
-    u.defer = false;
+    u.sup_stride = (long long)P.nslabS * u.slab;
+    if (P.ds4) { u.ds4 = true; u.slab = (long long)4 * N * P.ldS; u.sup_stride = 0; }   // one slab = the four blocks side by side
     u.Sstk = P.Sstk; u.STstk = P.STstk; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
-    if (P.mform) {
-        u.mform = true; u.nbm = P.nb;
-        for (int k = 0; k < P.nb; ++k) { u.Mf[k] = P.sup.mfrag[k]; u.Mtf[k] = P.sup.mfrag[4 + k]; }
-        u.slab = (long long)P.nb * N * P.ldS;          // one slab = the nb output blocks side by side
-        u.sup_stride = 0;
-    }
     return u;
 }
 
 // K splits of the N x N x N products of the T2 matrices and of their chain rule: 2 when the unsplit product leaves more than
 // a third of the CUs without a tile (and K is long enough for the launcher to make exactly 2, see bf16_eff_splits)
 static int t2_splits(int N) {
-    static const bool off = getenv("MCRN_T2_SPLIT") && atoi(getenv("MCRN_T2_SPLIT")) == 0;
     const long long tiles = (long long)cdiv(N, 256) * cdiv(N, 128);
-    return !off && !bf16_cfg_is_sk(g_force_cfg_bf16) && tiles <= 170 && N >= 512 && bf16_eff_splits(1, N, 2) == 2 ? 2 : 1;
+    return !bf16_cfg_is_sk(g_force_cfg_bf16) && tiles <= 170 && N >= 512 && bf16_eff_splits(1, N, 2) == 2 ? 2 : 1;
 }
 // MCRN_BF16, once per forward: the stacked bf16 operands.  T2(S) = 2 S S - I (model/MegaCRN.py:20-22) is itself a
 // bf16-resident product: A = the S block of the stack just built (rows, K-contiguous), B = the same block read as [k][n].
@@ -2128,12 +1893,12 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
         }
     }
     const bool wps = P.wpimg[0] != nullptr;
-    if (lite && !wps) FAIL("bf16-resident planes need the streaming weight pool (MCRN_WP_STREAM=0 with MCRN_BF16_PLANES on)");
+    if (lite && !wps) FAIL("bf16-resident planes need the streaming weight pool");
     if (wps)
         for (int i = 0; i < 4; ++i) {
             const Shp& sh_ = i < 2 ? se : sd;
             ++g_launches;
-            CK(launch_wp_img_build(P.Wf[i], sh_.Cp, sh_.H, sh_.d, P.nb, Os[i], sh_.R, P.wpimg[i], ps, sh_.fused ? 2 : 0));
+            CK(launch_wp_img_build(P.Wf[i], sh_.Cp, sh_.H, sh_.d, P.nb, Os[i], sh_.R, P.wpimg[i], ps, 0));
         }
     // decoder input columns (:181-183): covariates, zero pad columns, go symbol = 0; the state columns of Zdec[0] are
     // written by the memory head after the encoder
@@ -2145,7 +1910,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, sd.C, sd.Cp, R, To, ps));
     CKI(zero_cols(P.Zdec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));   // go = 0 (:182)
     CKI(zero_cols(P.Ydec, sd.ZT, sd.Cp, Hd, Hd + od, R, 1, ps));
-    if ((sd.hoist || sd.fused || sd.hoist_fwd) && To > 1) {
+    if ((sd.hoist || sd.hoist_fwd) && To > 1) {
         // the go symbol of step t+1 is labels[:, t] wherever step t is teacher-forced (:188-191): known now, so it takes
         // part in the hoisted propagation of the decoder's input channels; the other steps' go columns are zero until
         // their projection writes them (their planes are then propagated per step, below)
@@ -2157,7 +1922,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
             CKI(zero_cols(P.Ydec + sd.ZT, sd.ZT, sd.Cp, Hd, Hd + od, R, To - 1, ps));
         }
     }
-    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st, P.mform ? d->cheb_k : 0));
+    CKI(sup_fwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.ldS, P.sup.g2, !P.bf16, st));
     Sup u = model_sup(P, N);
     if (P.bf16) CKI(build_stacks(P, u, N, d->cheb_k, st));
     // ---- encoder (MegaCRN.py:65-83): inputs for all t packed once
@@ -2173,9 +1938,6 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     if (P.bf16) {   // t-invariant part of the propagation: the input channels of every step, once per stack
         CKI(hoist_inputs(se, u, P.Zenc, P.Yenc, Ti, H, din, P.xin_b, P.xin_t, st, P.Xp_e));
         CKI(hoist_inputs(sd, u, P.Zdec, P.Ydec, To, Hd, od + yd, P.xin_b, P.xin_t, st, P.Xp_d));
-    } else if (se.fused) {
-        CKI(hoist_inputs_small(se, u, P.Zenc, P.Yenc, Ti, H, se.Cp - H, P.xin_f, st));
-        CKI(hoist_inputs_small(sd, u, P.Zdec, P.Ydec, To, Hd, sd.Cp - Hd, P.xin_f, st));
     } else if (sd.hoist_fwd && any_teacher) {
         // decoder input / pad channels of every step in one product (steps whose go symbol is not known yet contribute zeros here
         // and are propagated at full width below, which rewrites their columns)
@@ -2218,27 +1980,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
         // go = proj(h') was not known when the decoder's input channels were hoisted: propagate this one channel block now
         if (P.bf16 && !last && !lab) CKI(hoist_inputs(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_b, P.xin_t, st,
                                                      P.Xp_d ? P.Xp_d + (long long)(t + 1) * P.nb * R * 4 : nullptr));
-        if (!P.bf16 && sd.fused && !last && !lab) CKI(hoist_inputs_small(sd, u, Zn, P.Ydec + (t + 1) * sd.ZT, 1, Hd, od, P.xin_f, st));
     }
-    return 0;
-}
-
-// one deferred adjacency-gradient launch for a cell stack: slabs [slab0, slab0 + chunks) of both supports
-static int ds_deferred(const ModelPlan& P, const Shp& s, int T, const float* dPall, const float* Yall,
-                       const float* Zall, int slab0, int N, hipStream_t st) {
-    DsDefP q;
-    memset(&q, 0, sizeof q);
-    const long long slab = (long long)N * P.ldS;
-    const long long sup_stride = (long long)(P.nslabS + P.ndef_d) * slab;
-    (void)slab0;
-    q.dPall = dPall; q.Xall[0] = Yall; q.Xall[1] = Zall;
-    q.slabs[0] = P.dS + (long long)P.nslabS * slab;
-    q.slabs[1] = P.dS + sup_stride + (long long)P.nslabS * slab;
-    q.slab = slab; q.PS = s.PS; q.ZT = s.ZT; q.ld = s.ld; q.ldc = P.ldS;
-    q.T = T; q.K = s.K; q.N = N; q.ncols = (int)s.ld;
-    const int nseg = s.K == 3 ? 2 : 1;
-    const double ex = (double)T * 2 * nseg * 2.0 * 2.0 * (double)N * N * (double)s.ld;
-    MCRN_PROF_WRAP(ROLE_DS, launch_ds_deferred(q, st), ex, (double)T * 2 * nseg * 2.0 * 2.0 * (double)N * N * (double)s.B * s.C);
     return 0;
 }
 
@@ -2253,7 +1995,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     const Shp &se = P.se, &sd = P.sd;
     const long long R = se.R;
     Sup u = model_sup(P, N);
-    CK(hipMemsetAsync(P.dS, 0, (size_t)(P.mform ? P.nb : 2) * (P.nslabS + P.ndef_d) * N * P.ldS * sizeof(float), st));
+    CK(hipMemsetAsync(P.dS, 0, (size_t)(P.ds4 ? 4 : 2) * P.nslabS * N * P.ldS * sizeof(float), st));
     CK(hipMemsetAsync(P.dWq_s, 0, (size_t)NSLAB_T * H * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dMem_s, 0, (size_t)NSLAB_T * M * D * sizeof(float), st));
     CK(hipMemsetAsync(P.dWp_s, 0, (size_t)NSLAB_T * od * Hd * sizeof(float), st));
@@ -2271,8 +2013,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CK(hipMemsetAsync(P.dPin_e, 0, (size_t)(P.nb * N + 64) * P.kin_e * sizeof(uint16_t), st));
         CK(hipMemsetAsync(P.dPin_d, 0, (size_t)(P.nb * N + 64) * P.kin_d * sizeof(uint16_t), st));
     }
-    // ---- decoder BPTT (its adjacency gradient is deferred to one launch after the loop when possible)
-    Sup ud = u; ud.defer = P.defer_ds;
+    // ---- decoder BPTT
+    const Sup& ud = u;
     CellW wd{P.Wf[2], P.Wd[2], p->dec_gate_b, P.Wf[3], P.Wd[3], p->dec_update_b, P.imgf[2], P.imgd[2], P.imgf[3], P.imgd[3]};
     {
         int xu = 0, xg = 0;
@@ -2288,8 +2030,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             // was known before the stack started - zero (t = 0) or the label of a teacher-forced step (no use_next at t - 1)
             Shp sdt = sd;
             sdt.state_only = sd.hoist_bwd && any_teacher && (t == 0 || teacher[t - 1]);
-            float* dPt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 0) * sd.ZT : P.dPp[pair];
-            float* dQt = P.defer_ds ? P.dPall_d + ((long long)t * 2 + 1) * sd.ZT : P.dQp[pair];
+            float* dPt = P.dPp[pair];
+            float* dQt = P.dQp[pair];
             if (last) {
                 LAUNCH(k_proj_bwd, dim3(cdiv(R * Hd, 256)), dim3(256), 0, st, d_output + (long long)t * N * od,
                        (long long)To * N * od, (long long)od, (const float*)P.dxin_d, (long long)(od + yd), use_next,
@@ -2300,7 +2042,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                 CKI(cell_bwd_ca(sd, (bh || prev_hoisted) ? Hd : sd.Cp, dPprev, dQprev, P.dTu, P.dTg, xu, xg, d_output + (long long)t * N * od,
                                 (long long)To * N * od, (long long)od, use_next, p->proj_w, od, P.dgo + (long long)t * R * od,
                                 P.Zdec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
-                                P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st, propt_partials_bf16(sd, bh)));
+                                P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, P.dacc_d, st));
             }
             CKI(cell_bwd_core(sdt, ud, P.Zdec + t * sd.ZT, P.Ydec + t * sd.ZT, P.zr_d + t * R * 2 * Hd, P.hc_d + t * R * Hd,
                               wd, P.dhn_d, P.dU_d + t * R * Hd, P.dG_d + t * R * 2 * Hd, dPt, dQt, P.dacc_d, P.dxin_d, st,
@@ -2317,10 +2059,9 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     float* part_ = P.part;
     if (g_use_side && !g_tuning && g_prof.role < 0) {
         CKI(side_init());
-        // Second helper queue (MCRN_SIDE2=0: the first one, as before round 4).  On the first queue the encoder's adjacency-
-        // gradient launches waited behind these ~0.5 ms of HBM streaming, the plane-set guards of the main queue behind them.
-        static const bool side2_off = getenv("MCRN_SIDE2") && atoi(getenv("MCRN_SIDE2")) == 0;
-        const bool two = !side2_off && !P.bf16 && !P.defer_ds;
+        // Second helper queue on the small graphs.  On the first queue the encoder's adjacency-gradient launches waited behind these
+        // ~0.5 ms of HBM streaming, the plane-set guards of the main queue behind them (profiles/r4/experiments.md section 11).
+        const bool two = !P.bf16;
         hipStream_t hs = two ? g_side.st2 : g_side.st;
         CK(hipEventRecord(two ? g_side.fork2 : g_side.fork, st));         // (its own event: ready[0] belongs to the per-call launches of the loops)
         CK(hipStreamWaitEvent(hs, two ? g_side.fork2 : g_side.fork, 0));
@@ -2339,10 +2080,6 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                (long long)od * Hd, (long long)od * Hd, 0);
         CKI(colsum(P.dgo, od, To * R, od, part_, g->proj_b, 0, ws_));
     }
-    if (P.defer_ds) {
-        hipStream_t st = ws_;
-        CKI(ds_deferred(P, sd, To, P.dPall_d, P.Ydec, P.Zdec, 0, N, st));
-    }
     int ns1 = 0;
     bool on1 = false, on2 = false, on3 = false, on4 = false;
     const bool lite = P.bf16 && P.Pb_e != nullptr;
@@ -2353,12 +2090,11 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // keeps the other half: METR-LA 10 950 vs 10 700 / 10 630 and 10 780 / 10 805 vs 10 633 / 10 625 samples/s, PEMS-BAY 6 425 vs
     // 6 314 / 6 299 (two calls; 72 workgroups: slower again - profiles/r4/experiments.md).  The bf16 mode measured no difference
     // (its helper stream runs beside MFMA-bound products) and keeps the full width.
-    static const int wg_env = getenv("MCRN_WGRAD_DEC_WGS") ? atoi(getenv("MCRN_WGRAD_DEC_WGS")) : 0;
     // Round 4, second step: on their OWN queue (Side::st2) they no longer hold up the encoder's adjacency-gradient launches, and
     // there the narrower the better until they stop fitting the encoder BPTT: 24 workgroups (budget 32) -> METR-LA 11 026 / 10 995
     // vs 10 781 (one helper queue, 120 workgroups) and 10 633 before; PEMS-BAY 6 314 / 6 276 vs 6 184; 12 workgroups: 9 410.
     const bool own_queue = g_side.ok && ws_ == g_side.st2;
-    const int dec_budget = ws_ != st ? (wg_env > 0 ? wg_env : (P.bf16 ? NSLAB_W : (own_queue ? 32 : NSLAB_W / 2))) : NSLAB_W;
+    const int dec_budget = ws_ != st ? (P.bf16 ? NSLAB_W : (own_queue ? 32 : NSLAB_W / 2)) : NSLAB_W;
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     int ns2 = 0;
     CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
@@ -2390,11 +2126,6 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st));
         return 0;
     };
-    bool ds_dec_done = false;
-    // (opt-in: measured neutral at N = 1843 and N = 8192 - 4273 vs 4261 and 120.5 vs 123.4 samples/s - the product is
-    //  MFMA-bound and full-chip, so it only trades places with the BPTT kernels it overlaps)
-    static const bool ds_side_on = getenv("MCRN_BF16_DS_SIDE") && atoi(getenv("MCRN_BF16_DS_SIDE")) == 1;
-    if (bh && ws_ != st && ds_side_on) { CKI(stack_ds(0, ws_)); ds_dec_done = true; }
     CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1, on1 ? g->dec_gate_b : nullptr));
     CKI(wunprep(g->dec_update_w, P.dWs[3], sd, Hd, ws_, ns2, on2 ? g->dec_update_b : nullptr));
     if (!on1) CKI(colsum(P.dG_d, 2 * Hd, To * R, 2 * Hd, part_, g->dec_gate_b, 0, ws_));
@@ -2418,7 +2149,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)
                 CKI(cell_bwd_ca(se, bh ? H : se.Cp, P.dPp[prev], P.dQp[prev], P.dTu, P.dTg, xu, xg, nullptr, 0, 0, 0, nullptr, 0, nullptr,
                                 P.Zenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H,
-                                P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st, propt_partials_bf16(se, bh)));
+                                P.dU_e + t * R * H, P.dG_e + t * R * 2 * H, P.dacc_e, st));
             CKI(cell_bwd_core(se, u, P.Zenc + t * se.ZT, P.Yenc + t * se.ZT, P.zr_e + t * R * 2 * H, P.hc_e + t * R * H, we,
                               P.dacc_e, P.dU_e + t * R * H, P.dG_e + t * R * 2 * H,
                               dPt, dQt, P.dacc_e, P.dxin_e, st, P.dTu, P.dTg, /*do_a=*/first, /*do_c=*/t == 0, &xu, &xg,
@@ -2431,8 +2162,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // the bf16 mode both go to the helper stream; on the small graphs the gate call's stays on the caller's stream (the
     // helper stream is still finishing the last cell's adjacency gradient) and the update call's goes to the helper stream.
     // The caller's stream then waits only for what the helper stream had BEFORE them (`mid`): the adjacency-gradient slabs.
-    static const bool tail_side_off = getenv("MCRN_TAIL_SIDE") && atoi(getenv("MCRN_TAIL_SIDE")) == 0;
-    const bool tail_side = g_use_side && !g_tuning && g_prof.role < 0 && !tail_side_off;
+    const bool tail_side = g_use_side && !g_tuning && g_prof.role < 0;
     hipStream_t wg_st = st, wu_st = st;
     float *part_g = P.part, *part_u = P.part;
     if (tail_side) {
@@ -2443,16 +2173,6 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         wu_st = g_side.st; part_u = P.part2;
         if (P.bf16) { wg_st = g_side.st; part_g = P.part2; }
         g_side.any = true;
-        // small graphs with the second helper queue, OPT-IN (MCRN_TAIL2=1: measured neutral, 11 061 / 11 065 vs 11 062 / 11 046 samples/s
-        // at METR-LA): the gate call's weight gradient (130 us) leaves the caller's tail too and runs beside the chain of tiny
-        // launches of the adjacency backward
-        static const bool tail2_on = getenv("MCRN_TAIL2") && atoi(getenv("MCRN_TAIL2")) == 1;
-        static const bool side2_off = getenv("MCRN_SIDE2") && atoi(getenv("MCRN_SIDE2")) == 0;
-        if (!P.bf16 && !P.defer_ds && tail2_on && !side2_off) {
-            CK(hipEventRecord(g_side.fork2, st));
-            CK(hipStreamWaitEvent(g_side.st2, g_side.fork2, 0));
-            wg_st = g_side.st2; part_g = P.part3; g_side.any2 = true;
-        }
     }
     int ns3 = 0;
     CKI(agcn_wgrad(se, P.Zenc, se.ZT, Ti, P.dG_e, 2 * H, P.dWs[0], wg_st, &ns3, &on3, lite ? P.Pb_e : nullptr, 2 * PbS_e, (long long)N * se.ldh, P.Xp_e));
@@ -2469,7 +2189,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         // one K-concatenated product per cell stack over every AGCN call's (dP planes, centred input plane), then the
         // chain rule of T2 = 2 S S - I; the S blocks of dA then hold dS1 / dS2
         if (bh) {
-            if (!ds_dec_done) CKI(stack_ds(0, st));
+            CKI(stack_ds(0, st));
             CKI(stack_ds(1, st));
         } else {
         CKI(centre_planes(sd, u, P.Zdec, P.Ydec, To, P.x0c_d, st));
@@ -2480,33 +2200,33 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         CKI(t2_backward(P, u, N, d->cheb_k, st));
         CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dA,
                          P.dA + (long long)(d->cheb_k - 1) * N * P.ldS, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
-    } else if (P.mform) {
-        // matrix form: fold the slabs of all nb blocks (fixed order), then the chain rule of M2 = 2 S S onto S in exact fp32
-        //   dS_s = dA[S_s] + 2 (dM2_s S_s^T + S_s^T dM2_s)        (the "- I" of T2 carries no gradient)
+    } else if (P.ds4) {
+        // fold the slabs of the four blocks (fixed order), then the chain rule of T2 = 2 S S - I onto S in exact fp32 (two batched N^3
+        // products of a few MFLOP):   dS_b = dA[d1_b] + dA[e2_b] S_b^T + S_b^T dA[e2_b]        (e2 = 2 d2 carries the factor 2)
         const long long nn = (long long)N * P.ldS;
-        LAUNCH(k_reduce_slabs, dim3(cdiv(P.nb * nn, 64)), dim3(1024), 0, st, P.dAm, (const float*)P.dS, P.nslabS, P.nb * nn, P.nb * nn, 0);
-        if (d->cheb_k == 3) {
+        LAUNCH(k_reduce_slabs, dim3(cdiv(4 * nn, 64)), dim3(1024), 0, st, P.dAm, (const float*)P.dS, P.nslabS, 4 * nn, 4 * nn, 0);
+        {
             ExactFp32 exact_chain;
             for (int which = 0; which < 2; ++which) {
                 GemmP q = gp();
-                q.M = N; q.N = N; q.K = N; q.nbatch = 2; q.alpha = 2.f; q.beta = 1.f;
+                q.M = N; q.N = N; q.K = N; q.nbatch = 2; q.beta = 1.f;
                 q.am = plain(P.ldS); q.ak = plain(1);
                 if (which == 0) { q.bk = plain(1); q.bn = plain(P.ldS); } else { q.bk = plain(P.ldS); q.bn = plain(1); }
                 q.cm = plain(P.ldS); q.cn = plain(1);
                 for (int b = 0; b < 2; ++b) {
-                    const float* dT = P.dAm + (long long)(2 * b + 1) * nn;
-                    q.A[b] = which == 0 ? dT : (b ? P.sup.St2 : P.sup.St1);            // dT S^T   |   S^T dT
-                    q.B[b] = which == 0 ? (b ? P.sup.g2 : P.sup.g1) : dT;
+                    const float* dE = P.dAm + (long long)(2 * b + 1) * nn;
+                    q.A[b] = which == 0 ? dE : (b ? P.sup.St2 : P.sup.St1);            // dE S^T   |   S^T dE
+                    q.B[b] = which == 0 ? (b ? P.sup.g2 : P.sup.g1) : dE;
                     q.C[b] = P.dAm + (long long)(2 * b) * nn; q.Cin[b] = q.C[b];
                 }
                 CKI(gemm(q, true, which == 0, 0, ROLE_MISC, st));
             }
         }
-        CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dAm,
-                         P.dAm + (long long)(d->cheb_k - 1) * nn, P.ldS, 1, 0, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
+        CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dAm, P.dAm + 2 * nn, P.ldS, 1, 0,
+                         g->We1, g->We2, P.dMem_s, st, NSLAB_T));
     } else
     CKI(sup_bwd_core(N, M, D, p->We1, p->We2, p->Memory, P.sup, P.sup.g1, P.sup.g2, P.ldS, P.dS, P.dS + u.sup_stride,
-                     P.ldS, P.nslabS + P.ndef_d, u.slab, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
+                     P.ldS, P.nslabS, u.slab, g->We1, g->We2, P.dMem_s, st, NSLAB_T));
     LAUNCH(k_reduce_slabs, dim3(cdiv(M * D, 64)), dim3(1024), 0, st, g->Memory, (const float*)P.dMem_s, NSLAB_T,
            (long long)M * D, (long long)M * D, 0);
     if (d_pos) LAUNCH(k_memory_scatter, dim3(cdiv(R * D, 256)), dim3(256), 0, st, g->Memory, (const int*)P.ind_rows, 0, d_pos, B, N, D);
@@ -2668,7 +2388,7 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
     mcrn_grads_t G = {gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9], gg[10], gg[11], gg[12], gg[13]};
     PrecisionScope prec(d->precision);
     g_tuning = true;
-    if (d->precision == MCRN_BF16 && !(getenv("MCRN_TUNE_COLD") && atoi(getenv("MCRN_TUNE_COLD")) == 0)) {
+    if (d->precision == MCRN_BF16) {
         g_flush_bytes = (size_t)192 << 20;
         if (hipMalloc(&g_flush, g_flush_bytes) != hipSuccess) { g_flush = nullptr; g_flush_bytes = 0; (void)hipGetLastError(); }
     }
@@ -2730,9 +2450,7 @@ int mcrn_autotune_import(const int* buf, long long n) {
             TuneKey k; memcpy(&k, buf + i + 2, sizeof k); a[k] = cfg;
         } else if (kind == 1) {
             if (cfg < 0 || cfg >= NCFG_BF16) FAIL("autotune_import: bf16 tile configuration %d out of range", cfg);
-            // stream-K tiles ignore the K split that the consumers of a split product count on (hoist_inputs, go_grad_bf16, the
-            // partial planes of the transposed propagation); the tuner never emits them, a peer's table must not either
-            if (bf16_cfg_is_sk(cfg)) FAIL("autotune_import: stream-K tile configuration %d is not importable", cfg);
+            if (bf16_cfg_is_sk(cfg)) FAIL("autotune_import: tile configuration %d is a retired slot", cfg);
             Bf16Key k; memcpy(&k, buf + i + 2, sizeof k); b[k] = cfg;
         } else {
             if (cfg < 1 || cfg > 1 + PROPT_MAX_X) FAIL("autotune_import: split count %d out of range", cfg);
@@ -2866,7 +2584,7 @@ int mcrn_agcn_forward(int B, int N, int C, int O, int cheb_k, const float* x, co
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N;
     CKI(wprep(W, P.Wf, P.Wd, s, O, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
     CKI(bnc_to_rows(P.Z, s.Cp, 0, C, x, B, N, st));
@@ -2887,7 +2605,7 @@ int mcrn_agcn_backward(int B, int N, int C, int O, int cheb_k, const float* dy, 
     AgcnPlan P;
     plan_agcn(B, N, C, O, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));
@@ -2922,7 +2640,7 @@ int mcrn_cell_forward(int B, int N, int din, int H, int cheb_k, const float* x, 
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N;
     CKI(wprep(gate_w, P.Wf[0], P.Wd[0], s, 2 * H, st));
     CKI(wprep(update_w, P.Wf[1], P.Wd[1], s, H, st));
     CKI(build_frags(s1, s2, N, N, P.frag, st));
@@ -2947,7 +2665,7 @@ int mcrn_cell_backward(int B, int N, int din, int H, int cheb_k, const float* dh
     CellPlan P;
     plan_cell(B, N, din, H, cheb_k, (char*)ws, P);
     const Shp& s = P.s;
-    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N; u.defer = false;
+    Sup u; u.S[0] = s1; u.S[1] = s2; u.St[0] = P.St1; u.St[1] = P.St2; u.Sf[0] = P.frag[0]; u.Sf[1] = P.frag[1]; u.Stf[0] = P.frag[2]; u.Stf[1] = P.frag[3]; u.Simg[0] = u.Simg[1] = u.Stimg[0] = u.Stimg[1] = nullptr; u.simg_n = 0; u.ldS = N; u.dS = P.dS; u.nslab = P.nslabS; u.slab = (long long)N * N; u.sup_stride = (long long)P.nslabS * N * N;
     CKI(transpose(P.St1, N, s1, N, nullptr, 0, N, st));
     CKI(transpose(P.St2, N, s2, N, nullptr, 0, N, st));
     CK(hipMemsetAsync(P.dS, 0, (size_t)2 * P.nslabS * N * N * sizeof(float), st));

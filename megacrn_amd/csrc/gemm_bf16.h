@@ -90,6 +90,9 @@ struct Bf16Tile {
     int tps;
     int iss_seg, iss_lt;                  // K tile the next DMA will fetch
 
+    // (Every workgroup walks its K tiles IN ORDER.  Round 5 tried a per-tile rotated start - workgroups that share an operand panel on one
+    //  XCD would then not ask for the same lines at the same time - and measured 20 - 25 % SLOWER on every product, harness and model: the
+    //  lock-step is what makes one fetch from the memory side serve every workgroup of the XCD.  profiles/r5/experiments.md section 3.)
     __device__ __forceinline__ void init(const Bf16GemmP& p, int tid, int m_blk, int n_blk, int kt_beg) {
         const long long a0 = rm_off(p.am, m_blk);
         baseA = p.A + a0;
@@ -129,6 +132,7 @@ struct Bf16Tile {
         stepA_seg = p.a_seg; stepB_seg = p.b_seg; tps = p.tps;
         iss_seg = kt_beg / p.tps; iss_lt = kt_beg - iss_seg * p.tps;
     }
+    __device__ __forceinline__ void advance() { if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; } }
     // DMA of the next K tile into LDS stage `stg`
     __device__ __forceinline__ void issue(unsigned lds_base, int stg, int wave) {
         const uint16_t* __restrict__ Ab = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
@@ -141,7 +145,7 @@ struct Bf16Tile {
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
             if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(Bb, offB[j], sB + j * NT * 16);
-        if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; }
+        advance();
     }
     // The same DMA in PIECES, for K loops that slip them between the MFMAs of the tile being multiplied: a wave that issues
     // its 6 - 8 pieces back to back waits 60 - 180 cycles per piece for the address path with the matrix pipe idle
@@ -164,7 +168,7 @@ struct Bf16Tile {
             if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(pcB, offB[j], pcsB + j * NT * 16);
         }
     }
-    __device__ __forceinline__ void issue_end() { if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; } }
+    __device__ __forceinline__ void issue_end() { advance(); }
 };
 // which DMA piece (if any) follows MFMA number m of a tile's NM: the NP pieces are spread evenly, the first one early
 __device__ __forceinline__ constexpr int bf16_piece_after(int m, int NM, int NP) {
@@ -280,12 +284,10 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
                                               int lane) {
     const int l31 = lane & 31, kq = lane >> 5;
     const long long soff = p.slab2 > 0 ? (split > 0 ? p.slab + (long long)(split - 1) * p.slab2 : 0) : (long long)split * p.slab;
-    const bool pb = p.Cpb != nullptr && split > 0;                   // this split's result is a packed bf16 partial plane only
-    float* __restrict__ C = (p.C && !pb) ? p.C + soff : nullptr;
-    const float* __restrict__ Cin = (p.Cin && !pb && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
-    uint16_t* __restrict__ Cbp = pb ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb;
+    float* __restrict__ C = p.C ? p.C + soff : nullptr;
+    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
-    const int ld = (int)p.cm.lo, ldb = pb ? p.pb_ld : (int)p.cbm.lo;
+    const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
     const bool cols_in = cw + 32 * FN <= p.N;
     // column offset of fragment j (scalar): contiguous columns, or the two-level map of cn_inner / cn_hi - a 32-column
     // fragment never straddles an inner block (cn_inner % 32 == 0, fragments start at multiples of 32)
@@ -303,7 +305,7 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
         const unsigned lo0 = (unsigned)(4 * kq * ld + l31);
         float* __restrict__ Cf = C ? C + base : nullptr;
         const float* __restrict__ Cif = Cin ? Cin + base : nullptr;
-        uint16_t* __restrict__ Cbf = Cbp ? Cbp + (long long)rb * ldb + cw : nullptr;
+        uint16_t* __restrict__ Cbf = p.Cb ? p.Cb + (long long)rb * ldb + cw : nullptr;
         const unsigned lb0 = (unsigned)(4 * kq * ldb + l31);
         if (cols_in && rb + 32 <= p.M) {                             // whole fragment inside: straight-line code
 #pragma unroll
@@ -483,11 +485,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         }
         if (++rd == NSTAGE) rd = 0;
     }
-    const bool pbw = p.Cpb != nullptr && split > 0 && p.wide_pb;    // workgroup-uniform (split is)
-    if ((p.wide_cb || pbw) && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
+    if (p.wide_cb && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
         __syncthreads();                                         // every wave is done reading the operand stages
-        if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128),
-                                       pbw ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb, pbw ? p.pb_ld : (int)p.cbm.lo)) return;
+        if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128), p.Cb, (int)p.cbm.lo)) return;
     }
     bf16_epilogue<FM, FN>(p, acc, split, m_blk + wm * WM, n_blk + wn * WN, lane);
 }
@@ -645,138 +645,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     MCRN_CLK_PROBE(0);
     L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
     MCRN_CLK_PROBE(1);
-    const bool pbw = p.Cpb != nullptr && split > 0 && p.wide_pb;    // workgroup-uniform (split is)
-    if ((p.wide_cb || pbw) && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
+    if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
-        if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128),
-                                             pbw ? p.Cpb + (long long)(split - 1) * p.pb_slab : p.Cb, pbw ? p.pb_ld : (int)p.cbm.lo)) return;
+        if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128), p.Cb,
+                                             (int)p.cbm.lo)) return;
     }
     bf16_epilogue<L::FM, L::FN>(p, acc, split, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Kernel 3, stream-K over the ping-pong loop: ONE workgroup per CU, each takes an equal share of the (tile, K tile)
-// units instead of whole tiles, so a product whose tile count is not a multiple of the CU count (261 tiles of
-// 256 x 256 for the N = 1843 propagation: two rounds, the second 2 % full) or far below it (72 tiles, K = 4 x 1843
-// for its transpose) still keeps every CU busy for the same time.
-//   * the tiles are dealt to the 8 XCDs first (contiguous ranges, as in bf16_tile_of); the 32 workgroups of an XCD
-//     split THAT range's units evenly - all workgroups that share a tile share an L2;
-//   * a workgroup walks its unit range from the top: first the piece that does NOT reach the end of its tile (at most
-//     one): raw accumulators -> its workspace slot, flag = epoch; then whole tiles; last the piece that ends a tile
-//     begun by lower-numbered workgroups: it waits for their flags, adds their partials in a fixed order (bitwise
-//     reproducible) and runs the epilogue.  Waits only ever point at lower blockIdx.x of the same launch, which the
-//     dispatcher started earlier: no deadlock however few workgroups are resident.
-// ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
-__global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(const Bf16GemmP p) {
-    using L = PpLoop<BM, BN, BK, NSTAGE, BTR>;
-    constexpr int FM = L::FM, FN = L::FN;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16);
-    const int wm = wave / L::WGN, wn = wave % L::WGN;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nblk = tiles_m * tiles_n;
-    const int nkt = p.nseg * p.tps;
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, J = gridDim.x >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int ntx = q + (x < r ? 1 : 0);                          // tiles of this XCD: [tx0, tx0 + ntx)
-    const int tx0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    const long long Ux = (long long)ntx * nkt;                    // its units, split evenly over its J workgroups
-    const int u0 = (int)(Ux * j / J), u1 = (int)(Ux * (j + 1) / J);
-
-    int aoff[FM], boff[FN];
-    bf16_frag_offsets<FM, FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
-    f32x16_t acc[FM][FN];
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    constexpr int SLOT4 = BM * BN / 4;                            // float4 per workspace slot
-    f32x4_t* __restrict__ ws4 = reinterpret_cast<f32x4_t*>(p.sk_ws);
-
-    int u_hi = u1;
-    while (u_hi > u0) {
-        // The K loop uses every VGPR.  Whatever the epilogue / fix-up derive from the lane id must be formed AFTER it,
-        // per piece: an opaque copy keeps the compiler from hoisting ~200 address registers out of this loop into
-        // scratch (and a launch with that much scratch costs tens of microseconds in the runtime).
-        int lane_p = tid & 63;
-        asm volatile("" : "+v"(lane_p));
-        const int frag0 = (wave * (FM * FN * 4)) * 64 + lane_p;   // slot layout: [wave][fragment][quarter][lane] float4
-        const int t = (u_hi - 1) / nkt, ts = t * nkt;
-        const int lo = max(u0, ts);
-        const bool owner = u_hi - ts == nkt;
-        int tile_m, tile_n;
-        bf16_tile_coords(tx0 + t, tiles_m, tiles_n, tile_m, tile_n);
-        const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-        L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, lo - ts, u_hi - lo, aoff, boff, acc);
-        if (!owner) {
-            // partial tile -> workspace with agent-scope (sc1) stores: written through to the memory side, visible to
-            // every XCD without flushing this XCD's whole L2 (what a release fence would do)
-            f32x4_t* dst = ws4 + (long long)blockIdx.x * SLOT4 + frag0;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < FN; ++jn) {
-                    f32x4_t* d = dst + (i * FN + jn) * 4 * 64;
-                    const f32x4_t v0 = {acc[i][jn][0], acc[i][jn][1], acc[i][jn][2], acc[i][jn][3]};
-                    const f32x4_t v1 = {acc[i][jn][4], acc[i][jn][5], acc[i][jn][6], acc[i][jn][7]};
-                    const f32x4_t v2 = {acc[i][jn][8], acc[i][jn][9], acc[i][jn][10], acc[i][jn][11]};
-                    const f32x4_t v3 = {acc[i][jn][12], acc[i][jn][13], acc[i][jn][14], acc[i][jn][15]};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
-                                 "global_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
-                                 "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\t"
-                                 "global_store_dwordx4 %0, %4, off offset:3072 sc1"
-                                 :: "v"(d), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
-                }
-            MCRN_VMCNT(0);
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lo > ts) {                                        // the tile began in lower-numbered workgroups of this XCD
-                for (int jj = j - 1; jj >= 0; --jj) {
-                    const int a1 = (int)(Ux * (jj + 1) / J);
-                    if (a1 <= ts) break;
-                    if ((int)(Ux * jj / J) == a1) continue;       // (no units: wrote nothing)
-                    const int g2 = (jj << 3) | x;
-                    if (tid == 0)
-                        while (__hip_atomic_load(p.sk_flag + g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch)
-                            __builtin_amdgcn_s_sleep(2);
-                    __syncthreads();
-                    // agent-scope (sc1) loads: never served from a stale line of this XCD's L2, no cache invalidate
-                    const f32x4_t* src = ws4 + (long long)g2 * SLOT4 + frag0;
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        f32x4_t v[FN][4];
-#pragma unroll
-                        for (int jn = 0; jn < FN; ++jn) {
-                            const f32x4_t* q4 = src + (i * FN + jn) * 4 * 64;
-                            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                                         "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                                         "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
-                                         "global_load_dwordx4 %3, %4, off offset:3072 sc1"
-                                         : "=&v"(v[jn][0]), "=&v"(v[jn][1]), "=&v"(v[jn][2]), "=&v"(v[jn][3]) : "v"(q4) : "memory");
-                        }
-                        // the wait names every destination, so no use can be scheduled in front of it
-                        static_assert(FN == 2 || FN == 1, "operand list below");
-                        if constexpr (FN == 2)
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
-                                         "+v"(v[FN - 1][0]), "+v"(v[FN - 1][1]), "+v"(v[FN - 1][2]), "+v"(v[FN - 1][3]) :: "memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) :: "memory");
-#pragma unroll
-                        for (int jn = 0; jn < FN; ++jn)
-#pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) {
-                                acc[i][jn][4 * qq] += v[jn][qq][0]; acc[i][jn][4 * qq + 1] += v[jn][qq][1];
-                                acc[i][jn][4 * qq + 2] += v[jn][qq][2]; acc[i][jn][4 * qq + 3] += v[jn][qq][3];
-                            }
-                    }
-                }
-            }
-            bf16_epilogue<FM, FN>(p, acc, 0, m_blk + wm * L::WM, n_blk + wn * L::WN, lane_p);
-        }
-        __syncthreads();                                          // acc consumed, LDS stages free for the next piece
-        u_hi = lo;
-    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -830,56 +704,6 @@ static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
-// stream-K workspace: one per stream (launches on one stream are ordered; two streams may run two of them at once)
-struct SkWs { float* ws; int* flag; int epoch; int G; };
-static SkWs* sk_workspace(hipStream_t st, hipError_t& err) {
-    static SkWs tab[8];
-    static hipStream_t key[8];
-    static int n = 0;
-    err = hipSuccess;
-    for (int i = 0; i < n; ++i)
-        if (key[i] == st) return &tab[i];
-    if (st == (hipStream_t)-1) {                                  // release request
-        for (int i = 0; i < n; ++i) { (void)hipFree(tab[i].ws); (void)hipFree(tab[i].flag); }
-        n = 0;
-        return nullptr;
-    }
-    if (n == 8) { err = hipErrorOutOfMemory; return nullptr; }
-    int dev = 0, cus = 0;
-    if ((err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
-    if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return nullptr;
-    SkWs w;
-    w.G = cus & ~7; w.epoch = 0;
-    if (w.G < 8) { err = hipErrorInvalidValue; return nullptr; }
-    if ((err = hipMalloc(&w.ws, (size_t)w.G * 256 * 256 * sizeof(float))) != hipSuccess) return nullptr;
-    if ((err = hipMalloc(&w.flag, (size_t)w.G * sizeof(int))) != hipSuccess) return nullptr;
-    if ((err = hipMemsetAsync(w.flag, 0, (size_t)w.G * sizeof(int), st)) != hipSuccess) return nullptr;
-    key[n] = st; tab[n] = w;
-    return &tab[n++];
-}
-void bf16_gemm_release_workspaces() { hipError_t e; (void)sk_workspace((hipStream_t)-1, e); }
-
-template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
-static inline hipError_t launch_one_bf16_sk(Bf16GemmP p, hipStream_t st) {
-    static_assert(BM * BN <= 256 * 256, "workspace slot");
-    bf16_split_plan(p, BK, 1);
-    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
-    static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipError_t e;
-    SkWs* w = sk_workspace(st, e);
-    if (!w) return e;
-    p.sk_ws = w->ws; p.sk_flag = w->flag; p.sk_epoch = ++w->epoch;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(w->G), dim3(512), lds, st, p);
-    return hipGetLastError();
-}
 template <bool BTR, int ROLE>
 static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
@@ -893,9 +717,7 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
         case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
         case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
         case 9: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
-        case 10: return launch_one_bf16_sk<256, 256, 64, 2, BTR, ROLE>(p, st);             // 128 KB   1   stream-K
-        case 11: return launch_one_bf16_sk<256, 128, 64, 2, BTR, ROLE>(p, st);             //  96 KB   1   stream-K
-        case 12: return launch_one_bf16_sk<192, 256, 64, 2, BTR, ROLE>(p, st);             // 112 KB   1   stream-K
+        case 10: case 11: case 12: return hipErrorInvalidValue;                           // retired slots (round 2's stream-K tiles, removed in round 5)
         // FOUR waves (one per SIMD), 128 x 64 wave tiles: a 32K-output tile - the size that fills 256 CUs in one round on
         // the hoisted N = 1843 encoder product (7372 x 1024: 232 tiles) - read with 0.75 LDS fragment reads per MFMA, like
         // the 256 x 256 eight-wave tile (the eight-wave 256 x 128 forms have 64 x 64 or 128 x 32 wave tiles: 1.0 / 1.25)
@@ -913,11 +735,9 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
     if (btr && ((p.N & 7) || p.N < 8)) return hipErrorInvalidValue;     // [k][n] operands are fetched in 8-column chunks
     if (p.cn_inner > 0 && ((p.cn_inner & 31) || p.Cb)) return hipErrorInvalidValue;   // a fragment must not straddle an inner block
     {
-        static const bool wide_off = getenv("MCRN_BF16_WIDE_EPI") && atoi(getenv("MCRN_BF16_WIDE_EPI")) == 0;
-        p.wide_cb = (!wide_off && p.Cb && !p.C && !p.Cin && p.nsplit <= 1 && nsplit <= 1 && (p.cbm.lo & 7) == 0 &&
+        p.wide_cb = (p.Cb && !p.C && !p.Cin && p.nsplit <= 1 && nsplit <= 1 && (p.cbm.lo & 7) == 0 &&
                      ((uintptr_t)p.Cb & 15) == 0) ? 1 : 0;
     }
-    p.wide_pb = (p.Cpb && (p.pb_ld & 7) == 0 && (p.pb_slab & 7) == 0 && ((uintptr_t)p.Cpb & 15) == 0) ? 1 : 0;
     // each hot role uses one storage form of B; everything else is "misc"
     if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
     if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);

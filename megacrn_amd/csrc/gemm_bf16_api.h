@@ -42,16 +42,8 @@ struct Bf16GemmP {
                               //      whose first slab is the real output and whose further slabs are a separate run of planes
     uint16_t* Cb;             // optional bf16 copy of the result (row map cbm)
     RowMap cbm;
-    uint16_t* Cpb;            // split-K with bf16 PARTIAL planes (round 5: the transposed propagation): split 0 takes the fp32 path above
-    long long pb_slab;        // (C / Cin / slab rules unchanged), split z >= 1 writes ONLY a packed bf16 matrix [M][pb_ld] at
-    int pb_ld;                // Cpb + (z - 1) * pb_slab - half the bytes of an fp32 partial plane, full 128-byte lines; the consumers
-    int wide_pb;              // add the partials in a fixed order.  wide_pb: set by the launcher (LDS-staged 16-byte stores possible)
     int xcd;                  // 1: XCD-aware tile order
     int wide_cb;              // set by the launcher: bf16-only output staged through LDS into 16-byte stores
-    // stream-K configurations only (launch_gemm_bf16 fills them from the per-stream workspace it owns)
-    float* sk_ws;             // one BM x BN fp32 partial tile per workgroup
-    int* sk_flag;             // one word per workgroup: epoch of the partial it last published
-    int sk_epoch;
     // host side only (bench.py's roofline leg): when set, the launch attaches these two events to the dispatch itself
     // (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end - what rocprofv3 reports - instead
     // of the span between two separately recorded event packets (~3 us longer per launch)
@@ -65,13 +57,10 @@ static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 2
                                            {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1},
                                            {256, 256, 1}, {256, 128, 1}, {192, 256, 1},
                                            {256, 128, 1}, {128, 256, 1}, {256, 192, 1}};
-// Configurations CFG_BF16_SK0 .. CFG_BF16_SK1 - 1 are stream-K (one output, nsplit ignored).  They are NOT in the tuner's
-// candidate set: measured (profiles/r2/kbench_streamk.txt) they only tie the best ping-pong configuration on the N = 1843
-// products - the fp32 partial tiles have to cross XCDs through the memory side (256 KB written + read per workgroup, ~25 us
-// of a ~55 us ideal) - so they stay an opt-in (MCRN_BF16_CFG=10..12) and a harness case.
+// Slots CFG_BF16_SK0 .. CFG_BF16_SK1 - 1 are RETIRED (round 2's stream-K tiles: they only tied the best ping-pong configuration on the
+// N = 1843 products - profiles/r2/kbench_streamk.txt - and were removed in round 5).  The indices stay reserved so that tile tables
+// keep their meaning; the tuner skips them, a table naming one is refused, forcing one (MCRN_BF16_CFG) fails the launch.
 static const int CFG_BF16_SK0 = 10, CFG_BF16_SK1 = 13;
 static inline bool bf16_cfg_is_sk(int c) { return c >= CFG_BF16_SK0 && c < CFG_BF16_SK1; }
-// frees the stream-K workspaces (library teardown / tests)
-void bf16_gemm_release_workspaces();
 
 }  // namespace mcrn

@@ -93,7 +93,6 @@ struct PropP {
 
 struct Prop2P {
     const uint4* Sf[2];         // forward: S1,S2 fragments ; backward: S1^T,S2^T fragments
-    const uint4* Mf[2];         // prop2m_fwd_kernel only (prop_mform.h: harness experiment, not in the library): fragments of 2 S1 S1, 2 S2 S2
     float* base;                // plane set (Z for forward, dP for backward)
     float* extra;               // backward: support 1 stores S_2^T d1t_2 here (consumers add it to dP[0])
     long long PS, ld;
@@ -103,27 +102,16 @@ struct Prop2P {
     // H = 64 * cps state channels of sample u / cps inside its row of cstride = Cp floats; the input / pad channels of the planes
     // 1 .. 4 come from a once-per-stack product (engine.hip: hoist_inputs_small)
     int nunits, cps, cstride;
-};
-
-// matrix-form single-hop propagation (prop_mform.h): group y (grid.y) multiplies the blocks y*nseg .. y*nseg + nseg - 1
-struct Prop1P {
-    const uint4* Sf[4];         // fragment image (k_sfrag_build layout) of block k: forward [S1, 2 S1 S1, S2, 2 S2 S2], backward their transposes
-    const float* src[4];        // right operand plane of block k (N x ncols, row stride ld)
-    float* out[4];              // output plane of group y
-    const float* add0[4];       // fp32 addends of group y (nullable) ...
-    const float* add1[4];
-    float coef0[4], coef1[4];   // ... and their factors (+1: the accumulating plane, -1: the "- I" of a T2 block)
-    int ny, nseg, N, ncols;
-    long long ld;
-    void *ev0, *ev1;            // host side only (see Prop2P)
-    // gathered units (cstep > 4): a unit's 32*CT columns are 8*CT column QUADS cstep floats apart (the d input / pad channels of
-    // consecutive samples, cstep = Cp); unit u starts at column col0 + u * 8*CT * cstep; nunits of them.  cstep = 0 / 4: contiguous.
-    int cstep, col0, nunits;
+    // backward: 1 = d1t_s = d1_s + S_s^T e2_s is NOT written back to plane 1 + 2s.  The adjacency gradient of the fused model path reads
+    // the raw d-grad planes (round 5: dS = d1 x0^T and e2 x0^T as four blocks, the chain rule of 2 S S once per step), so d1t lives only
+    // in this kernel's LDS image between its two hops: two plane writes less per launch.
+    int no_d1;
 };
 
 struct DsP {
-    // [output block][segment].  Feature-recursion path: block = support, 2 segments per AGCN call at cheb_k = 3 (d1t x0^T, e2 x1^T).
-    // Matrix form (prop_mform.h): block = Chebyshev block k < nb, ONE segment per call (dP_k x0^T).  A cell's two calls share one launch.
+    // [output block][segment].  Feature-recursion form (stand-alone ops, cheb_k = 2): block = support, 2 segments per AGCN call at
+    // cheb_k = 3 (d1t x0^T, e2 x1^T).  Fused model path at cheb_k = 3 (round 5): FOUR blocks [d1_a, e2_a, d1_b, e2_b] x x0^T, one segment
+    // per call - plane 0 is the only right operand (5 planes read instead of 7).  A cell's two calls share one launch.
     const float* A[4][4];
     const float* B[4][4];
     float* C[4];                // slab 0 of the block; slab z at + z*slab
@@ -132,15 +120,6 @@ struct DsP {
     long long ld, ldc;
 };
 
-struct DsDefP {
-    const float* dPall;          // [T][2 (0 = update AGCN, 1 = gate AGCN)][G planes]   gradient planes
-    const float* Xall[2];        // [0] = Y plane sets (update AGCN inputs), [1] = Z plane sets (gate), [T][G planes]
-    float* slabs[2];             // per support: slab z at + z*slab
-    long long slab, PS, ZT, ld, ldc;
-    int T, K, N, ncols;
-};
-
-static inline int ds_deferred_chunks(int ncols) { return (ncols + 63) / 64; }
 static inline bool prop_small_ok(int N, long long ld, int ncols) {
     return N <= 256 && (ncols % 4) == 0 && (ld % 4) == 0;
 }
@@ -153,24 +132,6 @@ static inline size_t sfrag_uint4(int N) {
     const int NF = (N + 31) / 32;
     return (size_t)NF * 2 * NF * 2 * 64;
 }
-
-// ---- one AGCN call of a small graph as one launch (agcn_fused.h) ------------------------------------------------
-enum AgcnEpi { AGF_GATE = 1, AGF_UPDATE = 2 };
-struct AgcnFP {
-    const uint4* Sf[2];       // fragment-ordered split adjacency of both supports (k_sfrag_build)
-    float* Z;                 // plane set: plane 0 = input [h | x | pad] (read), planes 1 .. 4 written (state columns)
-    long long PS, ld;         // plane stride, row stride (= B * Cp)
-    int N, B, H, d, Cp, O;
-    const uint4* Wimg;        // wp_stream.h weight image built with 2 column fragments per block
-    const float* bias;
-    int epi;                  // AGF_GATE: O = 2H ; AGF_UPDATE: O = H
-    float* out;               // GATE: zr [R][2H] ; UPDATE: hc [R][H]
-    float* out2;              // GATE: z*h (columns < H) ; UPDATE: h'   (row stride out2_ld)
-    long long out2_ld;
-    const float* hsrc;        // UPDATE: previous state h[r * hsrc_ld + c]
-    long long hsrc_ld;
-    const float* zr;          // UPDATE: the gate call's out
-};
 
 // ---- streaming d-grad (dgrad_stream.h) -----------------------------------------------------------------------
 static inline size_t wfrag_uint4(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * 64; }
@@ -208,13 +169,9 @@ hipError_t launch_prop_small(const PropP& p, int nbatch, hipStream_t st);
 hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st);
 hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st);
 hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int nblk = 2);
-hipError_t launch_prop1(const Prop1P& p, int ct, bool stream, int cap, hipStream_t st);
 // fragment images of n <= 8 matrices (S or S^T each) in one launch
 hipError_t launch_sfrag_multi(const float* const* S, const int* transpose, uint4* const* out, int n, long long ldS, int N, hipStream_t st);
-hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st);
 hipError_t launch_sfrag(const float* S, long long ldS, int N, int transpose, uint4* out, hipStream_t st);
-bool agcn_fused_ok(int N, int H, int d, int O, long long ld, int Cp);
-hipError_t launch_agcn_fused(const AgcnFP& p, hipStream_t st);
 hipError_t launch_dgrad_stream(DgradP p, hipStream_t st);
 // B-fragment image of Wd for the streaming d-grad (k_wfrag_build in dgrad_stream.h)
 hipError_t launch_wfrag_build(const float* W, long long ld, int rows, int K, int KS, uint4* out, long long tot, hipStream_t st);

@@ -660,22 +660,20 @@ __global__ void k_cell_bwd_b(const float* __restrict__ dy0, const float* __restr
 // C: dh_prev = dacc + dZ0[state] ; dxin = dY0[input] + dZ0[input]
 // (xcols: the extra partial planes cover columns < xcols only - all Cp columns, or just the state channels when the
 //  transposed propagation was hoisted)
-// (xbf: the partials are packed bf16 matrices of the state channels, see ld4_partial; xcols == H then)
 __global__ void k_cell_bwd_c(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
                              const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, int xcols, long long ld,
-                             int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin, int xbf) {
+                             int H, int d, long long R, float* __restrict__ dacc, float* __restrict__ dxin) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int C = H + d;
     if (i >= R * C) return;
     int c = (int)(i % C);
     long long r = i / C;
     float a = dz0[r * ld + c];
-    if (c < xcols) for (int e = 0; e < nzx; ++e)
-        a += xbf ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(dz0x)[e * xs + r * H + c] << 16) : dz0x[e * xs + r * ld + c];
+    if (c < xcols) for (int e = 0; e < nzx; ++e) a += dz0x[e * xs + r * ld + c];
     if (c < H) dacc[r * H + c] += a;
     else {
         float b = dy0[r * ld + c];
-        if (c < xcols && !xbf) for (int e = 0; e < nyx; ++e) b += dy0x[e * xs + r * ld + c];
+        if (c < xcols) for (int e = 0; e < nyx; ++e) b += dy0x[e * xs + r * ld + c];
         dxin[r * d + (c - H)] = a + b;
     }
 }
@@ -729,20 +727,6 @@ __global__ void k_cell_bwd_ca(const float* __restrict__ dz0, const float* __rest
 static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 static __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-// four consecutive bf16 values (8-byte aligned) widened to fp32
-static __device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
-}
-// Extra partial sums of plane 0 behind a cell's gradient planes (see k_cell_bwd_b): fp32 planes in the plane-0 layout
-// (XBF = false: element (r, c) of partial e at x[e * xs + r * ld + c]) or, bf16 mode with a split transposed propagation (round 5),
-// PACKED bf16 matrices of the state channels only (XBF = true: (const unsigned short*)x [e * xs + r * H + c], c < H)
-template <bool XBF>
-static __device__ __forceinline__ float4 ld4_partial(const float* x, int e, long long xs, long long r, long long ld, int H, int c) {
-    if (XBF) return ld4_bf16(reinterpret_cast<const unsigned short*>(x) + e * xs + r * H + c);
-    return ld4(x + e * xs + r * ld + c);
-}
-template <bool XBF>
 __global__ void k_cell_bwd_b4(const float* __restrict__ dy0, const float* __restrict__ dy0x, int nx, long long xs, long long ldy,
                               const float* __restrict__ z0, long long ldz, const float* __restrict__ zr, int H,
                               long long R, float* __restrict__ dG, float* __restrict__ dacc) {
@@ -752,13 +736,12 @@ __global__ void k_cell_bwd_b4(const float* __restrict__ dy0, const float* __rest
     const int c = 4 * (int)(i % H4);
     const long long r = i / H4;
     float4 dzh = ld4(dy0 + r * ldy + c);
-    for (int e = 0; e < nx; ++e) dzh = add4(dzh, ld4_partial<XBF>(dy0x, e, xs, r, ldy, H, c));
+    for (int e = 0; e < nx; ++e) dzh = add4(dzh, ld4(dy0x + e * xs + r * ldy + c));
     const float4 h = ld4(z0 + r * ldz + c), z = ld4(zr + r * 2 * H + c), a = ld4(dacc + r * H + c);
     st4(dG + r * 2 * H + c, make_float4(dzh.x * h.x * z.x * (1.f - z.x), dzh.y * h.y * z.y * (1.f - z.y),
                                         dzh.z * h.z * z.z * (1.f - z.z), dzh.w * h.w * z.w * (1.f - z.w)));
     st4(dacc + r * H + c, make_float4(a.x + dzh.x * z.x, a.y + dzh.y * z.y, a.z + dzh.z * z.z, a.w + dzh.w * z.w));
 }
-template <bool XBF>
 __global__ void k_cell_bwd_ca4(const float* __restrict__ dz0, const float* __restrict__ dz0x, int nzx,
                                const float* __restrict__ dy0, const float* __restrict__ dy0x, int nyx, long long xs, int xcols, long long ld,
                                const float* __restrict__ dout_bt, long long out_sb, long long out_sn, int use_next,
@@ -772,7 +755,7 @@ __global__ void k_cell_bwd_ca4(const float* __restrict__ dz0, const float* __res
     const int c = 4 * (int)(i % H4);
     const long long r = i / H4;
     float4 a = ld4(dz0 + r * ld + c);
-    for (int e = 0; e < nzx; ++e) a = add4(a, ld4_partial<XBF>(dz0x, e, xs, r, ld, H, c));
+    for (int e = 0; e < nzx; ++e) a = add4(a, ld4(dz0x + e * xs + r * ld + c));
     float4 g = add4(ld4(dacc + r * H + c), a);
     if (Wp) {
         const int n = (int)(r / B), b = (int)(r % B);
@@ -780,7 +763,7 @@ __global__ void k_cell_bwd_ca4(const float* __restrict__ dz0, const float* __res
             float go = dout_bt[b * out_sb + n * out_sn + j];
             if (use_next) {
                 float x = dz0[r * ld + H + j] + dy0[r * ld + H + j];
-                if (!XBF && H + j < xcols) {      // (packed bf16 partials hold the state channels only: xcols == H there)
+                if (H + j < xcols) {
                     for (int e = 0; e < nzx; ++e) x += dz0x[e * xs + r * ld + H + j];
                     for (int e = 0; e < nyx; ++e) x += dy0x[e * xs + r * ld + H + j];
                 }

@@ -42,6 +42,42 @@ static __global__ void k_sfrag_build(const float* __restrict__ S, long long ldS,
     out[((long long)(i * KS + ks) * 2 + 1) * 64 + lane] = l;
 }
 
+// fragment images (k_sfrag_build layout) of up to 8 matrices in ONE launch: blockIdx.y = which
+struct SfragMultiP {
+    const float* S[8];
+    uint4* out[8];
+    int transpose[8];
+    long long ldS;
+    int N, NF, n;
+};
+static __global__ void k_sfrag_build_multi(const SfragMultiP p) {
+    const int KS = 2 * p.NF;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.NF * KS * 64) return;
+    const int which = blockIdx.y;
+    const float* __restrict__ S = p.S[which];
+    const int transpose = p.transpose[which];
+    const int lane = idx & 63, ks = (idx >> 6) % KS, i = (idx >> 6) / KS;
+    const int row = 32 * i + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        v[j] = (row < p.N && k < p.N) ? (transpose ? S[(long long)k * p.ldS + row] : S[(long long)row * p.ldS + k]) : 0.f;
+    }
+    uint4 h, l;
+    split8(v, h, l);
+    uint4* __restrict__ out = p.out[which];
+    out[((long long)(i * KS + ks) * 2 + 0) * 64 + lane] = h;
+    out[((long long)(i * KS + ks) * 2 + 1) * 64 + lane] = l;
+}
+static inline hipError_t launch_sfrag_multi(const SfragMultiP& p, hipStream_t st) {
+    (void)hipGetLastError();
+    const int tot = p.NF * 2 * p.NF * 64;
+    hipLaunchKernelGGL(k_sfrag_build_multi, dim3((tot + 255) / 256, p.n), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 template <int NF>
 __global__ __launch_bounds__(64 * NF) void prop_small_kernel(const PropP p) {
     constexpr int KS = 2 * NF;                       // k-steps of 16
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
                 const bool ok = cok && (rows_in || row0 + MCRN_ROW_OF(v) < p.N);
                 const float d = ok ? acc[t][v] : 0.f;                 // zero rows / columns that do not exist
                 acc[t][v] = d;
-                if (ok) D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = d;
+                if (ok && !p.no_d1) D1[o + (unsigned)(MCRN_ROW_OF(v) * ld)] = d;   // (no_d1: nobody reads d1t - see Prop2P)
             }
         }
         MCRN_TL(1, 5);
@@ -922,130 +958,8 @@ static inline hipError_t launch_ds_small(DsP p, int nslab, hipStream_t st, int n
         // 256 < N <= 352: column groups of DS_WIDE_NJ fragments (grid.z)
         case 9: grid.z = (9 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<9, DS_WIDE_NJ>), grid, dim3(576), 0, st, p); break;
         case 10: grid.z = (10 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<10, DS_WIDE_NJ>), grid, dim3(640), 0, st, p); break;
-        case 11: {
-            // MCRN_DS_WIDE_NJ=6 (measurement): two column groups of 6 fragments instead of three of 4 (96 accumulator VGPRs: 22 spilled dwords)
-            static const bool nj6 = getenv("MCRN_DS_WIDE_NJ") && atoi(getenv("MCRN_DS_WIDE_NJ")) == 6;
-            if (nj6) { grid.z = 2; hipLaunchKernelGGL((ds_wide_kernel<11, 6>), grid, dim3(704), 0, st, p); }
-            else { grid.z = (11 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<11, DS_WIDE_NJ>), grid, dim3(704), 0, st, p); }
-            break;
-        }
+        case 11: grid.z = (11 + DS_WIDE_NJ - 1) / DS_WIDE_NJ; hipLaunchKernelGGL((ds_wide_kernel<11, DS_WIDE_NJ>), grid, dim3(704), 0, st, p); break;
         default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Deferred adjacency gradient (N <= 256): ONE launch per cell stack after its BPTT loop.
-// A workgroup owns a 64-column chunk and walks every time step, both AGCNs (update: planes of Y, gate:
-// planes of Z) and both segments (d1t x0^T, e2 x1^T), accumulating the whole N x N result of one support
-// in registers, and stores it exactly once into its own slab (plain stores: no atomics, no zero fill,
-// fixed summation order).  Per step this replaces 48 launches that each flushed a full N x N partial.
-// ---------------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(64 * NF) void ds_deferred_kernel(const DsDefP p) {
-    __shared__ uint4 img[2][NF][2][2][64];                  // one 32-column panel of both operands (see ds_small)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, kq = lane >> 5;
-    const int sup = blockIdx.y, z = blockIdx.x;
-    const int kbeg = z * 64;
-    const int kend = min(p.ncols, kbeg + 64);
-    const int npan = (kend - kbeg + 31) >> 5;               // 1 or 2 panels per (step, AGCN, segment)
-    const int nseg = p.K == 3 ? 2 : 1;
-    const int total = p.T * 2 * nseg * npan;
-    const long long g1 = 1 + (long long)sup * (p.K - 1);    // plane of S_s x / d1t of this support
-
-    f32x16 acc[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-
-    const int cq = tid & 7, r0 = tid >> 3;
-    float4 va[4], vb[4];
-    auto fetch = [&](int it) {
-        int q = it;
-        const int pi = q % npan; q /= npan;
-        const int seg = q % nseg; q /= nseg;
-        const int ag = q & 1, t = q >> 1;
-        const float* __restrict__ A = p.dPall + ((long long)t * 2 + ag) * p.ZT + (g1 + seg) * p.PS;         // d1t | e2
-        const float* __restrict__ B = p.Xall[ag] + (long long)t * p.ZT + (seg ? g1 * p.PS : 0);            // x0  | x1
-        const int k = kbeg + 32 * pi + 4 * cq;
-        const bool kv = k < kend;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = min(r0 + 8 * NF * i, p.N - 1);
-            va[i] = kv ? *reinterpret_cast<const float4*>(A + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vb[i] = kv ? *reinterpret_cast<const float4*>(B + (long long)r * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto publish = [&]() {
-        uint2* g = reinterpret_cast<uint2*>(&img[0][0][0][0][0]);
-        const int ks = cq >> 2, kq8 = (cq >> 1) & 1, half = cq & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 8 * NF * i;
-            const int fj = r >> 5, slot = (r & 31) + 32 * kq8;
-#pragma unroll
-            for (int op = 0; op < 2; ++op) {
-                const float4 x = op ? vb[i] : va[i];
-                const unsigned h01 = cvt_pk_bf16(x.x, x.y), h23 = cvt_pk_bf16(x.z, x.w);
-                const unsigned l01 = cvt_pk_bf16(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xFFFF0000u));
-                const unsigned l23 = cvt_pk_bf16(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xFFFF0000u));
-                const int base = (((op * NF + fj) * 2 + ks) * 2) * 64;
-                const int ps = slot ^ (kq8 << 1) ^ (ks << 2);                    // bank-conflict-free slot order (see ds_small_kernel)
-                g[(base + ps) * 2 + half] = make_uint2(h01, h23);
-                g[(base + 64 + ps) * 2 + half] = make_uint2(l01, l23);
-            }
-        }
-    };
-    fetch(0);
-    for (int it = 0; it < total; ++it) {
-        publish();
-        if (it + 1 < total) fetch(it + 1);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pl = lane ^ (kq << 1) ^ (ks << 2);
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, img[0][w][ks][0][pl]);
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, img[0][w][ks][1][pl]);
-            // product-outer order: the NF accumulators are independent chains
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, __builtin_bit_cast(bf16x8, img[1][j][ks][0][pl]), acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][1][pl]), acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, __builtin_bit_cast(bf16x8, img[1][j][ks][0][pl]), acc[j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    float* __restrict__ C = p.slabs[sup] + (long long)z * p.slab;
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int c = 32 * j + l31;
-        if (c >= p.N) continue;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = 32 * w + (v & 3) + 8 * (v >> 2) + 4 * kq;
-            if (r < p.N) C[(long long)r * p.ldc + c] = acc[j][v];
-        }
-    }
-}
-static inline hipError_t launch_ds_deferred(const DsDefP& p, hipStream_t st) {
-    (void)hipGetLastError();
-    const int NF = (p.N + 31) / 32;
-    dim3 grid(ds_deferred_chunks(p.ncols), 2);
-    switch (NF) {
-        case 1: hipLaunchKernelGGL(ds_deferred_kernel<1>, grid, dim3(64), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(ds_deferred_kernel<2>, grid, dim3(128), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(ds_deferred_kernel<3>, grid, dim3(192), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(ds_deferred_kernel<4>, grid, dim3(256), 0, st, p); break;
-        case 5: hipLaunchKernelGGL(ds_deferred_kernel<5>, grid, dim3(320), 0, st, p); break;
-        case 6: hipLaunchKernelGGL(ds_deferred_kernel<6>, grid, dim3(384), 0, st, p); break;
-        case 7: hipLaunchKernelGGL(ds_deferred_kernel<7>, grid, dim3(448), 0, st, p); break;
-        default: hipLaunchKernelGGL(ds_deferred_kernel<8>, grid, dim3(512), 0, st, p); break;
     }
     return hipGetLastError();
 }

@@ -301,17 +301,12 @@ static inline hipError_t launch_wgrad_one(const WgradP& p, hipStream_t st) {
     constexpr int WM = 8 / WN, MB = 32 * MFW * WM, NB = 32 * NFW * WN;
     constexpr int WA = MB, WB = 64 * ((NB + 63) / 64);
     constexpr size_t lds_need = (size_t)2 * 2 * (32 * WA * 2 + 32 * WB * 2);
-    // History of a wrong turn worth keeping: this kernel returned 1e-3-wrong weight gradients whenever
-    // another kernel's MFMA-dense waves shared its SIMDs (found by tests/test_gpu_parity.py::
-    // test_alternative_paths_keep_parity, reproduced with tools/kbench/wgrad_test CONC / MFMAN).  Not LDS, not the
-    // transposing reads, not the MFMA chains: the mask multiplications of fetch() had been SLP-vectorised into
-    // v_pk_mul_f32 / v_pk_fma_f32, and the HIGH half of a packed-fp32 VALU instruction comes back wrong under a foreign
-    // MFMA stream on the same SIMD (the probe builds -DMCRN_WGS_PROBE=1/2 showed the values wrong before they reach LDS).
-    // The whole library is now built with -fno-slp-vectorize -fno-vectorize (csrc/Makefile; tests/test_host_cpu.py checks
-    // the shipped code objects for packed-fp32 instructions).  MCRN_WGS_EXCL=1 asks for the whole LDS of a CU (nothing
-    // co-resident), the stop-gap used while the cause was unknown.
-    static const bool lds_excl = getenv("MCRN_WGS_EXCL") != nullptr;
-    const size_t lds = lds_excl ? (size_t)160 * 1024 : lds_need;
+    // (Round 2 saw 1e-3-wrong weight gradients from this kernel beside another stream's MFMA-dense waves and traced them to
+    //  SLP-vectorised v_pk_mul_f32 / v_pk_fma_f32 in fetch(); rounds 4 and 5 could no longer reproduce it on this pool - the control
+    //  binary with 9 000 packed-fp32 instructions is bit-identical in 0 of 12 x 8 runs, profiles/r5/experiments.md section 1 - so
+    //  the finding is retired.  The library keeps -fno-slp-vectorize -fno-vectorize because packed fp32 beside MFMAs measured
+    //  0.5 - 1.1 % SLOWER on every BASELINE config, same section.)
+    const size_t lds = lds_need;
     static_assert(lds_need <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {

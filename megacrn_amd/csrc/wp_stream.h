@@ -112,8 +112,15 @@ __global__ __launch_bounds__(256) void wp_stream_kernel(const WpP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kq = lane >> 5;
-    const int cb = blockIdx.y;
-    const long long r0 = (long long)blockIdx.x * 128 + 32 * w;
+    // The column blocks of a 128-row block run on ONE XCD (block b runs on XCD b % 8): they read the same operand rows - once from the
+    // memory side, then from that XCD's L2 (round 5, the d-grad's lesson: profiles/r5/experiments.md section 4).  1-D grid of
+    // ceil(row blocks / 8) * 8 * column blocks.
+    const int xcd = (int)(blockIdx.x & 7);
+    const long long slot = blockIdx.x >> 3;
+    const int cb = (int)(slot % p.ncb);
+    const long long rbk = (slot / p.ncb) * 8 + xcd;
+    if (rbk * 128 >= p.R) return;                                           // (padding of the last round; uniform over the workgroup)
+    const long long r0 = rbk * 128 + 32 * w;
     const long long rl = p.R - 1;
     const long long ra = min(r0 + l31, rl);                                 // row of this lane's A fragments (clamped)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.Wimg) + (long long)cb * (G * KSH + 1) * NBF * 2 * 1024;
@@ -286,7 +293,7 @@ static inline int wp_pick_nbf(int H, int O, long long R) {
         best = nbf;
         // (measured, METR-LA: 104 row blocks -> 208 workgroups per launch 6.26 ms/step, 416 6.12, 832 6.31; PEMS-BAY and
         //  EXPY-TKY unchanged between 160 and 300: with two workgroups per CU one's stage waits hide behind the other's MFMAs)
-        static const int minwg = getenv("MCRN_WP_MINWG") ? atoi(getenv("MCRN_WP_MINWG")) : 300;
+        const int minwg = 300;
         if (rb * (O / (32 * nbf)) >= minwg) break;
     }
     return best;
@@ -317,9 +324,12 @@ static inline hipError_t launch_wp_one(const WpP& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((unsigned)((p.R + 127) / 128), (unsigned)(p.O / (32 * NBF)));
+    WpP q = p;
+    q.ncb = p.O / (32 * NBF);
+    const long long nrb = (p.R + 127) / 128;
+    dim3 grid((unsigned)(((nrb + 7) / 8) * 8 * q.ncb));
     (void)hipGetLastError();
-    hipLaunchKernelGGL((wp_stream_kernel<KSH, NBP, NBF, EPI, PBF16>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((wp_stream_kernel<KSH, NBP, NBF, EPI, PBF16>), grid, dim3(256), lds, st, q);
     return hipGetLastError();
 }
 template <int KSH, int NBP, int EPI, bool PBF16>

@@ -31,6 +31,7 @@ struct WpP {
     const float* zr;          // UPDATE: the gate call's `out`
     const float* Xc;          // nullable: compact input channels of planes 1 .. nbp, [nbp][R][4] (k_scatter_compact) - then Z is read
     long long xc_plane;       //           for plane 0 only; stride between planes in floats (= 4 R)
+    int ncb;                  // set by the launcher: column blocks per row block (O / (32 NBF))
 };
 
 bool wp_stream_ok(int H, int d, int nbp, int O);

@@ -214,12 +214,18 @@ def test_ranks_adopt_rank0_tile_table_world2():
 
 def test_autotune_import_rejects_malformed_tables():
     from megacrn_amd import _lib
-    # (last: a stream-K bf16 tile, configurations 10..12 - it would ignore the K split its consumers count on)
+    # (last: a retired bf16 tile slot, configurations 10..12 - round 2's stream-K tiles, removed in round 5)
     for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 6] + [0] * 6 + [-1], [1, 6, 1, 7372, 1152, 1843, 1, 1, 11]):
         with pytest.raises(RuntimeError):
             _lib.autotune_import(bad)
-    _lib.autotune_import([])
+    _lib.lib.mcrn_autotune_clear()
+    _lib.autotune_import([])                      # (import merges into the table: nothing to merge, nothing there)
     assert _lib.autotune_export() == []
+    good = [1, 6, 1, 7372, 1152, 1843, 1, 1, 4]
+    _lib.autotune_import(good)
+    _lib.autotune_import([1, 6, 1, 7372, 2048, 1843, 1, 1, 9])          # a second shape: merged, the first one stays
+    assert len(_lib.autotune_export()) == 2 * len(good)
+    _lib.lib.mcrn_autotune_clear()
 
 
 def test_bench_self_launch_plumbing_gpus2(monkeypatch):

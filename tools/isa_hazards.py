@@ -34,69 +34,120 @@ def sregs(text):
     return out
 
 
+CARRY_OUT = ("v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale")      # VOP3 forms whose SECOND operand is an SGPR destination (carry / flag)
+
+
 def valu_sgpr_writes(ins):
-    """SGPRs written by a VALU instruction (first operand(s) of v_readfirstlane / v_readlane / compares and carry-outs
-    that name an SGPR destination)."""
+    """SGPRs written by a VALU instruction: ANY s-register among its destination operands - the first operand always
+    (v_readfirstlane / v_readlane / v_cmp* with an SGPR-pair destination / v_writelane is a VGPR write and has none), the second
+    operand too for the carry-out and flag forms (*_co_*, v_mad_u64_u32, v_mad_i64_i32, v_div_scale)."""
     m = re.match(r"^(v_\w+)\s+(.*)$", ins)
     if not m:
         return set()
     op, args = m.group(1), m.group(2).split(",")
-    if op.startswith(("v_readfirstlane", "v_readlane")):
-        return sregs(args[0])
-    if op.startswith("v_cmp") or op.startswith("v_div_scale") or "_co_" in op:
-        # VOP3 forms: an SGPR pair among the leading destination operands
-        dst = args[0] if op.startswith("v_cmp") else (args[1] if len(args) > 1 else "")
-        return sregs(dst)
-    return set()
+    out = sregs(args[0]) if args else set()
+    if len(args) > 1 and ("_co_" in op or op.startswith(CARRY_OUT)):
+        out |= sregs(args[1])
+    if op.startswith("v_cmpx"):
+        return set()                      # writes EXEC only
+    return out
+
+
+def _wait_states(ins):
+    m = re.match(r"^s_nop\s+(\d+)", ins)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def _vmem_saddr(ins):
+    """SGPRs of the scalar address operand of a VMEM instruction (empty for the "off" / VGPR-address forms)."""
+    vm = VMEM.match(ins)
+    if not vm:
+        return None
+    addr = set()
+    for p in [q.strip() for q in vm.group(2).split(",")][1:]:
+        p0 = p.split()[0] if p else ""
+        if re.fullmatch(r"s\[\d+:\d+\]", p0):
+            addr |= sregs(p0)
+    return addr
+
+
+def _check(ins, addr, history):
+    """history: (instruction, wait states) most recent LAST.  -> (writer, distance) of a hazard or None"""
+    dist, watch = 0, set(addr)
+    for prev, ws in reversed(history):
+        if valu_sgpr_writes(prev) & watch:
+            return (prev, dist) if dist < NEED else None
+        # a SALU instruction that (re)writes a watched register produced the value the load reads: SALU -> VMEM needs no wait
+        # states, and whatever wrote the register before it no longer matters
+        ms = re.match(r"^s_\w+\s+([^,]+)", prev)
+        if ms:
+            watch -= sregs(ms.group(1))
+            if not watch:
+                return None
+        dist += ws
+        if dist >= NEED:
+            return None
+    return None
+
+
+BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch)\s+(\d+)")
 
 
 def scan_disassembly(dis):
-    """-> list of (function, vmem instruction, writer instruction, wait states between them)"""
-    hits, func, window = [], "?", []      # window: (instruction text, wait states it provides), most recent last
+    """-> list of (function, vmem instruction, writer instruction, wait states between them).
+    Two passes per function: the linear instruction order, and every BRANCH EDGE - the instructions before a branch followed by
+    the instructions at its target (loop back-edges: the streamed-fragment issue blocks sit at the head of unrolled loops)."""
+    hits = []
+    funcs, cur = [], None
     for line in dis.split("\n"):
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
         if m:
-            func, window = m.group(1), []
+            cur = (m.group(1), [])
+            funcs.append(cur)
             continue
-        m = re.match(r"^\s+(\S.*?)\s*//", line)
+        m = re.match(r"^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", line)
         if not m:
+            m2 = re.match(r"^\s+(\S.*?)\s*//", line)
+            if m2 and cur is not None:
+                cur[1].append((None, m2.group(1).strip()))
             continue
-        ins = m.group(1).strip()
-        vm = VMEM.match(ins)
-        if vm:
-            # the SGPR address is the trailing s[a:b] operand (saddr form); "off" forms carry no SGPR
-            ops = vm.group(2)
-            tail = [p.strip() for p in ops.split(",")]
-            addr = set()
-            for p in tail[1:]:
-                p0 = p.split()[0] if p else ""
-                if re.fullmatch(r"s\[\d+:\d+\]", p0):
-                    addr |= sregs(p0)
+        if cur is None:
+            cur = ("?", [])
+            funcs.append(cur)
+        cur[1].append((int(m.group(2), 16), m.group(1).strip()))
+    for func, body in funcs:
+        index = {a: i for i, (a, _) in enumerate(body) if a is not None}
+        # pass 1: linear order
+        for i, (_, ins) in enumerate(body):
+            addr = _vmem_saddr(ins)
             if addr:
-                dist, watch = 0, set(addr)
-                for prev, ws in reversed(window):
-                    w = valu_sgpr_writes(prev)
-                    if w & watch:
-                        if dist < NEED:
-                            hits.append((func, ins, prev, dist))
-                        break
-                    # a SALU instruction that (re)writes a watched register produced the value the load reads: SALU -> VMEM
-                    # needs no wait states, and whatever wrote the register before it no longer matters
-                    ms = re.match(r"^s_\w+\s+([^,]+)", prev)
-                    if ms:
-                        watch -= sregs(ms.group(1))
-                        if not watch:
-                            break
-                    dist += ws
-                    if dist >= NEED:
-                        break
-        ws = 1
-        m2 = re.match(r"^s_nop\s+(\d+)", ins)
-        if m2:
-            ws = int(m2.group(1)) + 1
-        window.append((ins, ws))
-        if len(window) > 12:
-            window.pop(0)
+                h = _check(ins, addr, [(p, _wait_states(p)) for _, p in body[max(0, i - 12):i]])
+                if h:
+                    hits.append((func, ins, h[0], h[1]))
+        # pass 2: branch edges (taken): history = what precedes the branch (+ the branch), continuation = the target's first instructions
+        for i, (a, ins) in enumerate(body):
+            mb = BRANCH.match(ins)
+            if not mb or a is None:
+                continue
+            imm = int(mb.group(2))
+            if imm >= 0x8000:
+                imm -= 0x10000
+            t = index.get(a + 4 + 4 * imm)
+            if t is None:
+                continue
+            hist = [(p, _wait_states(p)) for _, p in body[max(0, i - 12):i + 1]]
+            dist = 0
+            for j in range(t, min(t + NEED, len(body))):
+                tin = body[j][1]
+                addr = _vmem_saddr(tin)
+                if addr:
+                    h = _check(tin, addr, hist)
+                    if h and (func, tin, h[0], h[1]) not in hits:
+                        hits.append((func, tin, h[0], h[1]))
+                hist = hist + [(tin, _wait_states(tin))]
+                dist += _wait_states(tin)
+                if dist >= NEED:
+                    break
     return hits
 
 

@@ -1,10 +1,9 @@
-// Stand-alone correctness + timing harness for megacrn_amd/csrc/prop_mform.h (matrix-form single-hop propagation) against
-// the fused two-hop kernels of prop_small.h (no torch).
+// Stand-alone correctness + timing harness of the small-graph propagation kernels (no torch): the fused two-hop kernels of
+// megacrn_amd/csrc/prop_small.h, forward and backward (with and without the d1t write-back), OUTSIDE the model's launch sequence.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-vectorize -o prop1_test prop1_test.hip
 //   ./prop1_test N ncols [reps]
-// Prints, per variant (ct, stream, groups x blocks-per-group, cap): max relative error vs a float64 CPU product of the same
-// inputs (forward and backward) and the average launch time over `reps` launches that rotate through NSET plane sets
-// (operands come from the memory side, as in a train step).
+// Prints, per kernel: max relative error vs a float64 CPU product of the same inputs and the average launch time over `reps`
+// launches that rotate through NSET plane sets (operands come from the memory side, as in a train step).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,7 +12,7 @@
 #include <vector>
 #include <random>
 #define MCRN_PROBE 1
-#include "../../megacrn_amd/csrc/prop_mform.h"
+#include "../../megacrn_amd/csrc/prop_small.h"
 using namespace mcrn;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -109,29 +108,41 @@ int main(int argc, char** argv) {
             }
         return e / m;
     };
-    auto fwd_params = [&](float* Z) {
-        Prop1P p; memset(&p, 0, sizeof p);
-        for (int k = 0; k < nb; ++k) {
-            p.Sf[k] = frag[k]; p.src[k] = Z; p.out[k] = Z + (size_t)(1 + k) * PS;
-            if (k & 1) { p.add0[k] = Z; p.coef0[k] = -1.f; }
-        }
-        p.ny = nb; p.nseg = 1; p.N = N; p.ncols = ncols; p.ld = ld;
-        return p;
-    };
-    auto bwd_params = [&](float* Z, int ny) {
-        Prop1P p; memset(&p, 0, sizeof p);
-        const int nseg = nb / ny;
-        for (int k = 0; k < nb; ++k) { p.Sf[k] = frag[4 + k]; p.src[k] = Z + (size_t)(1 + k) * PS; }
-        for (int y = 0; y < ny; ++y) {
-            p.out[y] = y == 0 ? Z : dX + (size_t)(y - 1) * PS;
-            if (y == 0) { p.add0[y] = Z; p.coef0[y] = 1.f; }
-            for (int sg = 0; sg < nseg; ++sg) {
-                const int k = y * nseg + sg;
-                if (k & 1) { p.add1[y] = Z + (size_t)(1 + k) * PS; p.coef1[y] = -1.f; }      // (one T2 block per group at most)
+    // recursion-form reference of prop2_bwd on the sampled columns:  d1t_s = D1_s + S_s^T E2_s ;  d0 = D0 + sum_s S_s^T d1t_s
+    std::vector<double> ref_d1t((size_t)2 * N * ncheck), ref_d0((size_t)N * ncheck);
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const float* S = hA.data() + (size_t)(2 * sidx) * N * N;
+        const float *D1 = Z0 + (size_t)(1 + 2 * sidx) * PS, *E2 = Z0 + (size_t)(2 + 2 * sidx) * PS;
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < ncheck; ++c) {
+                double a = D1[(size_t)i * ld + cols[c]];
+                for (int j = 0; j < N; ++j) a += (double)S[(size_t)j * N + i] * E2[(size_t)j * ld + cols[c]];
+                ref_d1t[((size_t)sidx * N + i) * ncheck + c] = a;
             }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int c = 0; c < ncheck; ++c) {
+            double a = Z0[(size_t)i * ld + cols[c]];
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const float* S = hA.data() + (size_t)(2 * sidx) * N * N;
+                for (int j = 0; j < N; ++j) a += (double)S[(size_t)j * N + i] * ref_d1t[((size_t)sidx * N + j) * ncheck + c];
+            }
+            ref_d0[(size_t)i * ncheck + c] = a;
         }
-        p.ny = ny; p.nseg = nseg; p.N = N; p.ncols = ncols; p.ld = ld;
-        return p;
+    auto check_bwd2 = [&](bool d1_written) -> double {      // got = plane set after prop2_bwd, gx = the extra plane
+        double e1 = 0, m1 = 0, e0 = 0, m0 = 0;
+        for (int sidx = 0; sidx < 2; ++sidx)
+            for (int i = 0; i < N; ++i)
+                for (int c = 0; c < ncheck; ++c) {
+                    const double want = d1_written ? ref_d1t[((size_t)sidx * N + i) * ncheck + c] : (double)Z0[(size_t)(1 + 2 * sidx) * PS + (size_t)i * ld + cols[c]];
+                    e1 = fmax(e1, fabs(want - got[(size_t)(1 + 2 * sidx) * PS + (size_t)i * ld + cols[c]])); m1 = fmax(m1, fabs(want));
+                }
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < ncheck; ++c) {
+                const double g = (double)got[(size_t)i * ld + cols[c]] + gx[(size_t)i * ld + cols[c]];
+                e0 = fmax(e0, fabs(ref_d0[(size_t)i * ncheck + c] - g)); m0 = fmax(m0, fabs(ref_d0[(size_t)i * ncheck + c]));
+            }
+        return fmax(e1 / m1, e0 / m0);
     };
     printf("N=%d ncols=%d NF=%d reps=%d (plane %.1f MB, %d rotating sets)\n", N, ncols, NF, reps, PS * 4 / 1e6, NSET);
     // ---- baseline: fused two-hop kernels (feature recursion; numerically the same planes)
@@ -146,78 +157,41 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  prop2_fwd (2 serial hops)           err %.2e   %.1f us\n", ef, 1e3 * ms / reps);
-        {   // matrix-form second term inside the fused kernel's workgroup shape (prop2m_fwd_kernel)
-            CK(reset());
-            Prop2P m = q; m.base = dZ; m.Mf[0] = frag[1]; m.Mf[1] = frag[3];
-            CK(launch_prop2m_fwd(m, 0));
-            CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
-            const double em = check_fwd();
+        if (N <= 352 && ncols % 132 == 0) {          // state columns only (decoder geometry: H = 128 of Cp = 132)
+            Prop2P q2 = q; q2.cps = 2; q2.cstride = 132; q2.nunits = (ncols / 132) * 2;
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < reps; ++r) { m.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2m_fwd(m, 0)); }
+            for (int r = 0; r < reps; ++r) { q2.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_fwd(q2, 0)); }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("  prop2m_fwd (S x0 | 2SS x0 - x0, one image)  err %.2e   %.1f us\n", em, 1e3 * ms / reps);
-            if (N <= 352 && ncols % 132 == 0) {          // state columns only (decoder geometry: H = 128 of Cp = 132)
-                m.base = dZ; m.cps = 2; m.cstride = 132; m.nunits = (ncols / 132) * 2;
-                CK(hipEventRecord(e0, 0));
-                for (int r = 0; r < reps; ++r) { m.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2m_fwd(m, 0)); }
-                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-                CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("  prop2m_fwd, state columns only (%d units)              %.1f us\n", m.nunits, 1e3 * ms / reps);
-                Prop2P q2 = q; q2.cps = 2; q2.cstride = 132; q2.nunits = (ncols / 132) * 2;
-                CK(hipEventRecord(e0, 0));
-                for (int r = 0; r < reps; ++r) { q2.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_fwd(q2, 0)); }
-                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-                CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("  prop2_fwd,  state columns only (%d units)              %.1f us\n", q2.nunits, 1e3 * ms / reps);
-            }
+            printf("  prop2_fwd,  state columns only (%d units)              %.1f us\n", q2.nunits, 1e3 * ms / reps);
         }
         CK(reset());
-        q.Sf[0] = frag[4]; q.Sf[1] = frag[6]; q.extra = dX;
+        q.Sf[0] = frag[4]; q.Sf[1] = frag[6]; q.extra = dX; q.base = dZ;
+        CK(launch_prop2_bwd(q, 0));
+        CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gx.data(), dX, (size_t)PS * 4, hipMemcpyDeviceToHost));
+        const double eb = check_bwd2(true);
+        CK(reset());
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < reps; ++r) { q.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_bwd(q, 0)); }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("  prop2_bwd (2 serial hops)                          %.1f us\n", 1e3 * ms / reps);
+        printf("  prop2_bwd (2 serial hops)           err %.2e   %.1f us\n", eb, 1e3 * ms / reps);
     }
-    if (getenv("P1_QUICK")) return 0;                  // baselines only
-    const int cts[3] = {2, 3, 4};
-    for (int stream = 0; stream < 2; ++stream)
-        for (int ci = 0; ci < 3; ++ci) {
-            const int ct = cts[ci];
-            if (NF > 8 && (ct != 2 || !stream)) continue;
-            const int nunits = (ncols + 32 * ct - 1) / (32 * ct);
-            const int caps[3] = {0, 64, 128};
-            for (int cpi = 0; cpi < 3; ++cpi) {
-                const int cap = caps[cpi];
-                if (cap && cap >= nunits) continue;
-                // forward
-                CK(reset());
-                Prop1P p = fwd_params(dZ);
-                CK(launch_prop1(p, ct, stream, cap, 0));
-                CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
-                const double ef = check_fwd();
-                CK(hipEventRecord(e0, 0));
-                for (int r = 0; r < reps; ++r) { Prop1P pr = fwd_params(dZ + (size_t)(r % NSET) * ZT); CK(launch_prop1(pr, ct, stream, cap, 0)); }
-                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("  fwd ct=%d stream=%d cap=%3d (%3d x 4 wgs)  err %.2e   %.1f us\n", ct, stream, cap, cap ? cap : nunits, ef, 1e3 * ms / reps);
-                // backward: 4 / 2 / 1 groups
-                for (int ny = 4; ny >= 2; ny >>= 1) {
-                    CK(reset());
-                    Prop1P b = bwd_params(dZ, ny);
-                    CK(launch_prop1(b, ct, stream, cap, 0));
-                    CK(hipMemcpy(got.data(), dZ, PS * 4, hipMemcpyDeviceToHost));
-                    CK(hipMemcpy(gx.data(), dX, (size_t)3 * PS * 4, hipMemcpyDeviceToHost));
-                    const double eb = check_bwd(ny - 1);
-                    CK(reset());
-                    CK(hipEventRecord(e0, 0));
-                    for (int r = 0; r < reps; ++r) { Prop1P br = bwd_params(dZ + (size_t)(r % NSET) * ZT, ny); CK(launch_prop1(br, ct, stream, cap, 0)); }
-                    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-                    CK(hipEventElapsedTime(&ms, e0, e1));
-                    printf("  bwd ct=%d stream=%d cap=%3d groups=%d x %d blocks   err %.2e   %.1f us\n", ct, stream, cap, ny, nb / ny, eb, 1e3 * ms / reps);
-                }
-            }
-        }
+    if (N <= PROP2_MAX_N) {   // the same chain without the d1t write-back (Prop2P::no_d1: the model path's form since round 5)
+        CK(reset());
+        Prop2P q; memset(&q, 0, sizeof q); q.Sf[0] = frag[4]; q.Sf[1] = frag[6]; q.base = dZ; q.extra = dX; q.PS = PS; q.ld = ld; q.N = N; q.ncols = ncols;
+        q.no_d1 = 1;
+        CK(launch_prop2_bwd(q, 0));
+        CK(hipMemcpy(got.data(), dZ, ZT * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gx.data(), dX, (size_t)PS * 4, hipMemcpyDeviceToHost));
+        const double en = check_bwd2(false);             // planes 1 and 3 must be untouched, plane 0 + extra as before
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        CK(hipEventRecord(a0, 0));
+        for (int r = 0; r < reps; ++r) { q.base = dZ + (size_t)(r % NSET) * ZT; CK(launch_prop2_bwd(q, 0)); }
+        CK(hipEventRecord(a1, 0)); CK(hipEventSynchronize(a1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, a0, a1));
+        printf("  prop2_bwd, no d1t write-back        err %.2e   %.1f us\n", en, 1e3 * ms / reps);
+    }
     return 0;
 }
