@@ -83,15 +83,16 @@ def pmc_traffic(config_name, dtype, N):
     d = traffic_profile(config_name, dtype)
     if d is None:
         return None
+    # (tools/pmc_traffic.sh folds the tile parameters of the tuned GEMMs away: family<*, operand forms, ROLE>)
     if dtype == "bf16":
-        keys = ("true, 1>",)                      # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
+        keys = ("gemm_bf16*<*, true, 1>",)        # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
     elif N <= 352 and dtype == "bf16x3":
         keys = ("prop2_fwd_kernel",)              # fused two-hop kernels (prop_small.h)
     else:
-        keys = ("true, false, 1>",)               # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
+        keys = ("<*, true, false, 1>",)           # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
     tot = n = 0
     for k, v in d.items():
-        if k != "_step" and any(key in k for key in keys) and ("gemm_bf16_" in k or dtype != "bf16"):
+        if k != "_step" and any(key in k for key in keys):
             tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None

@@ -372,12 +372,11 @@ static int nslab_S(int N) {
     // (256 < N <= 512, ds_wide_kernel at N <= 352: 12 -> 5 783, 16 -> 6 210, 24 -> 6 381, 32 -> 6 383, 48 -> 6 221 samples/s at PEMS-BAY)
     return N <= 512 ? 32 : (N <= 1024 ? 16 : (N <= 2048 ? 4 : 1));
 }
-// four-block form (Sup::ds4): 4 x nslab workgroups per launch, each with one K segment per call instead of two
-static int nslab_S4(int N) {
-    static const int env = getenv("MCRN_NSLAB_S4") ? atoi(getenv("MCRN_NSLAB_S4")) : 0;     // TEMPORARY sweep knob (round 5)
-    (void)N;
-    return env > 0 ? env : 16;
-}
+// four-block form (Sup::ds4): 4 x nslab workgroups per launch, each with one K segment per call instead of two.  Fewer, longer workgroups
+// leave CUs to the main queue (the launch runs on the helper stream) until the helper stream becomes the longer chain: same call,
+// METR-LA 12 -> 11 521, 16 -> 11 423, 20 -> 11 332, 32 -> 11 108 samples/s; PEMS-BAY 12 -> 6 670, 16 -> 6 762, 20 -> 6 676, 32 -> 6 603
+// (profiles/r5/experiments.md section 7)
+static int nslab_S4(int N) { return N <= 256 ? 12 : 16; }
 static const int NSLAB_W = 256;   // slab capacity of the deferred weight gradients (reduced by k_wunprep)
 static const int NSLAB_W_GEMM = 64;   // ... slabs the tiled-GEMM fallback splits K into
 static const int NSLAB_T = 256;   // split-K slabs of the tiny-output, very-long-K products (dWq, dMem, dWp): one tile, so K must fill the chip
@@ -637,6 +636,8 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.B = dPb; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PSb;
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
+    p.cin_pre = 1;                               // the K loop starts FROM plane 0: no read-modify-write epilogue (gemm_bf16.h, bf16_acc_preload;
+                                                 // 58.0 -> 55.8 us per launch, EXPY-TKY step +0.7 %: profiles/r5/experiments.md section 2)
     if (hoisted) { p.ldb = s.ldh; p.N = (int)s.ldh; p.b_seg = s.PSbh; p.cn_inner = s.H; p.cn_hi = s.Cp; }
     int nsplit = 1;
     const int split_env = 0;                                 // K splits: tuned (2 .. 4) with the tile
@@ -1519,8 +1520,7 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.nslabS = nslab_S(N);
     plan_sup(b, N, M, D, P.ldS, P.sup);
     // four-block adjacency gradient (Sup::ds4) wherever the fused two-hop chain and the output-stationary kernels take both cell shapes
-    static const bool ds4_off = getenv("MCRN_DS4") && atoi(getenv("MCRN_DS4")) == 0;        // TEMPORARY A/B knob (round 5)
-    P.ds4 = !ds4_off && d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
+    P.ds4 = d->precision == MCRN_BF16X3 && K == 3 && prop2_ok(N, P.se.ld, (int)P.se.ld) && prop2_ok(N, P.sd.ld, (int)P.sd.ld);
     if (P.ds4) P.nslabS = nslab_S4(N);
     P.dS = b.take<float>((size_t)(P.ds4 ? 4 : 2) * P.nslabS * N * P.ldS);   // split-K slabs of the adjacency gradient (per support / per block)
     P.dAm = P.ds4 ? b.take<float>((size_t)4 * N * P.ldS) : nullptr;         // ... the four reduced blocks

@@ -279,13 +279,54 @@ __device__ __forceinline__ bool bf16_epilogue_wide(const Bf16GemmP& p, f32x16_t 
     return true;
 }
 
+// Accumulators initialised with the addend (Bf16GemmP::cin_pre, round 5: the split-0 workgroups of the transposed propagation):
+//   acc = Cin   (alpha = beta = 1; elements outside the matrix: 0)
+// issued at kernel start, in front of the operand DMA of the prologue, so that the loads fly while the first K tiles arrive and the
+// epilogue only stores - the read-modify-write epilogue of these workgroups was the tail of the whole launch (profiles/r5/experiments.md
+// section 2).  Same addressing as bf16_epilogue; the loads are older than every DMA piece, so the kernels' counted vmcnt waits cover them.
+template <int FM, int FN>
+__device__ __forceinline__ void bf16_acc_preload(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int r_base, int c_base, int lane) {
+    const int l31 = lane & 31, kq = lane >> 5;
+    const float* __restrict__ Cin = p.Cin;
+    const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
+    const int ld = (int)p.cm.lo;
+    const bool cols_in = cw + 32 * FN <= p.N;
+    int cof[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int cj = cw + 32 * j;
+        cof[j] = p.cn_inner > 0 ? (cj / p.cn_inner) * p.cn_hi + (cj - (cj / p.cn_inner) * p.cn_inner) : cj;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int rb = rw + 32 * i;
+        const float* __restrict__ Cif = Cin + (long long)min(rb, p.M - 1) * ld;
+        const unsigned lo0 = (unsigned)(4 * kq * ld + l31);
+        if (cols_in && rb + 32 <= p.M) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = Cif[lo0 + (unsigned)(((v & 3) + 8 * (v >> 2)) * ld) + cof[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dr = (v & 3) + 8 * (v >> 2);
+                    const bool ok = rb + 4 * kq + dr < p.M && cw + 32 * j + l31 < p.N;
+                    acc[i][j][v] = ok ? Cin[(long long)(rb + 4 * kq + dr) * ld + l31 + cof[j]] : 0.f;
+                }
+        }
+    }
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc)[FM][FN], int split, int r_base, int c_base,
                                               int lane) {
     const int l31 = lane & 31, kq = lane >> 5;
     const long long soff = p.slab2 > 0 ? (split > 0 ? p.slab + (long long)(split - 1) * p.slab2 : 0) : (long long)split * p.slab;
     float* __restrict__ C = p.C ? p.C + soff : nullptr;
-    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0)) ? p.Cin + soff : nullptr;
+    const float* __restrict__ Cin = (p.Cin && !(p.cin_first_only && split > 0) && !p.cin_pre) ? p.Cin + soff : nullptr;   // (cin_pre: already in acc)
     const int rw = __builtin_amdgcn_readfirstlane(r_base), cw = __builtin_amdgcn_readfirstlane(c_base);
     const int ld = (int)p.cm.lo, ldb = (int)p.cbm.lo;
     const bool cols_in = cw + 32 * FN <= p.N;
@@ -388,12 +429,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
 
     f32x16_t acc[FM][FN];
+    if (p.cin_pre && split == 0) bf16_acc_preload<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane);      // workgroup-uniform
+    else {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    }
 
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
@@ -513,16 +557,18 @@ struct PpLoop {
     // registers; the caller puts a barrier between the use of acc and the next run() (LDS stages are reused).
     static __device__ __forceinline__ void run(const Bf16GemmP& p, unsigned char* smem, unsigned lds_base, int tid, int wave,
                                                int m_blk, int n_blk, int kt_beg, int nt, const int (&aoff)[FM],
-                                               const int (&boff)[FN], f32x16_t (&acc)[FM][FN]) {
+                                               const int (&boff)[FN], f32x16_t (&acc)[FM][FN], bool keep_acc = false) {
         const int grp = wave / WGN;                              // waves 0-3: group 0 (upper half of the tile), 4-7: group 1
         T tl;
         tl.init(p, tid, m_blk, n_blk, kt_beg);
+        if (!keep_acc) {                                         // (keep_acc: the caller preloaded the addend, bf16_acc_preload)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        }
 
         bf16x8_t fa[FM][KS], fb[FN][KS];
         bool first_load = true;
@@ -643,7 +689,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[L::FM][L::FN];
     MCRN_CLK_PROBE(0);
-    L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
+    const bool pre = p.cin_pre && split == 0;                     // workgroup-uniform
+    if (pre) bf16_acc_preload<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
+    L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc, pre);
     MCRN_CLK_PROBE(1);
     if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
@@ -738,6 +786,8 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
         p.wide_cb = (p.Cb && !p.C && !p.Cin && p.nsplit <= 1 && nsplit <= 1 && (p.cbm.lo & 7) == 0 &&
                      ((uintptr_t)p.Cb & 15) == 0) ? 1 : 0;
     }
+    if (p.cin_pre && !(p.Cin && p.C && p.alpha == 1.f && p.beta == 1.f && (p.nsplit <= 1 || p.cin_first_only) && (nsplit <= 1 || p.cin_first_only)))
+        return hipErrorInvalidValue;                                    // (the preload IS the addend: no scaling, split 0 only)
     // each hot role uses one storage form of B; everything else is "misc"
     if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
     if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);

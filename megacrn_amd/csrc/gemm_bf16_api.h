@@ -32,6 +32,7 @@ struct Bf16GemmP {
     float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
     const float* Cin;         // nullable
     int cin_first_only;       // split-K: only split 0 adds Cin (the other splits write plain partial results)
+    int cin_pre;              // 1: the workgroups that add Cin start their K loop FROM it (accumulators preloaded; alpha = beta = 1)
     RowMap cm;                // C row m -> element offset, columns contiguous unless cn_inner > 0
     int cn_inner;             // > 0: column j of C sits at (j / cn_inner) * cn_hi + j % cn_inner (cn_inner % 32 == 0): the
     int cn_hi;                //      h-channel block of every (node, sample) row of a plane set [n][b][Cp]; applies to C, Cin

@@ -106,6 +106,7 @@ struct Prop2P {
     // the raw d-grad planes (round 5: dS = d1 x0^T and e2 x0^T as four blocks, the chain rule of 2 S S once per step), so d1t lives only
     // in this kernel's LDS image between its two hops: two plane writes less per launch.
     int no_d1;
+    int nblk;                   // forward, set by the launcher: unit ranges per support (the grid is 1-D, see prop2_fwd_kernel)
 };
 
 struct DsP {

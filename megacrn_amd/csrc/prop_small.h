@@ -374,7 +374,12 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
     uint4* const img = prop2_img;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = blockIdx.y;
+    // 1-D grid of 16 * ceil(nblk / 8) workgroups: block b -> XCD b % 8, slot b / 8 -> (support = slot & 1, unit range (slot / 2) * 8 + XCD).
+    // The two supports of a unit range stage the SAME columns of plane 0: they share one XCD's L2 (round 5; with grid.y = support they
+    // landed on different XCDs whenever the range count is not a multiple of 8 - the METR-LA encoder: 68)
+    const int s = (int)((blockIdx.x >> 3) & 1);
+    const int bxi = (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
+    if (bxi >= p.nblk) return;                         // (padding of the last round; uniform over the workgroup)
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
     const float* __restrict__ X0 = p.base;
@@ -388,12 +393,12 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     uint4 ah[PB::NAL], al[PB::NAL];
     const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
     const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;   // (kept live only where the fragments are streamed)
-    const int ks0 = PB::WIDE ? (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS) : 0;
+    const int ks0 = PB::WIDE ? (int)((bxi * 7 + s * 3) % KS) : 0;
     MCRN_TL(0, 0);
     PB::load_a(sfw0, ah, al);
     MCRN_TL(0, 1);
     const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
-    const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    const int u0 = (int)(((long long)bxi * nunits) / p.nblk), u1 = (int)(((long long)(bxi + 1) * nunits) / p.nblk);
     for (int unit = u0; unit < u1; ++unit) {
         // (state columns only: the unit's 64 columns sit inside one sample's row of cstride floats, see Prop2P)
         const int colbase = p.nunits > 0 ? (unit / p.cps) * p.cstride + (unit % p.cps) * 32 * CT : unit * 32 * CT;
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
     }   // unit loop
 #ifdef MCRN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) g_tl[0][(blockIdx.y * gridDim.x + blockIdx.x) & 511][9] = wall_clock64();
+    if (threadIdx.x == 0) g_tl[0][blockIdx.x & 511][9] = wall_clock64();
 #endif
 }
 
@@ -651,9 +656,11 @@ static inline hipError_t launch_prop2_fwd(const Prop2P& p, hipStream_t st) {
         const int passes = (p.nunits + 127) / 128;
         ct = 2; blocks = (p.nunits + passes - 1) / passes;
     }
-    dim3 grid(blocks, 2);
-    if (ct == 3) { MCRN_NF_SWITCH8(prop2_fwd_kernel, 3, grid, p) }
-    else { MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, p) }
+    Prop2P q = p;
+    q.nblk = blocks;
+    dim3 grid(16 * ((blocks + 7) / 8));
+    if (ct == 3) { MCRN_NF_SWITCH8(prop2_fwd_kernel, 3, grid, q) }
+    else { MCRN_NF_SWITCH(prop2_fwd_kernel, 2, grid, q) }
     return hipGetLastError();
 }
 static inline hipError_t launch_prop2_bwd(const Prop2P& p, hipStream_t st) {

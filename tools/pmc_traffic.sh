@@ -19,6 +19,18 @@ tag = sys.argv[1]
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
 
 
+def norm(n):
+    """The two passes are two runs with two tile autotunes: a tiled GEMM of the same role may run a different tile configuration in each.
+    Tile parameters are folded away; what identifies a launch is the kernel family, its operand forms and its ROLE."""
+    m = re.match(r"^(gemm_f32_kernel|gemm_bf16x3_kernel)<.*, (true|false), (true|false), (\d+)>$", n)
+    if m:
+        return f"{m.group(1)}<*, {m.group(2)}, {m.group(3)}, {m.group(4)}>"
+    m = re.match(r"^gemm_bf16(?:_pp)?_kernel<.*, (true|false), (\d+)>$", n)
+    if m:
+        return f"gemm_bf16*<*, {m.group(1)}, {m.group(2)}>"
+    return n
+
+
 def step_window(counter):
     """[(kernel name, value)] of the last train step of one pass, in dispatch order"""
     rows = []
@@ -26,7 +38,7 @@ def step_window(counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mcrn::", "").replace("mcrn::", "")
+            n = norm(re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void mcrn::", "").replace("mcrn::", ""))
             rows.append((int(r["Dispatch_Id"]), n, float(r["Counter_Value"])))
     if not rows:
         sys.exit(f"pmc_traffic: no {counter} rows collected for {tag}")
@@ -38,11 +50,16 @@ def step_window(counter):
 
 
 fetch, write = step_window("FETCH_SIZE"), step_window("WRITE_SIZE")
-if [n for n, _ in fetch] != [n for n, _ in write]:
-    sys.exit(f"pmc_traffic: the two passes of {tag} did not launch the same step ({len(fetch)} vs {len(write)} dispatches)")
-acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for (n, f), (_, w) in zip(fetch, write):
-    a = acc[n]; a[0] += 1; a[1] += f; a[2] += w
+# (the two passes are two runs: the same launches, but dispatch ids of the helper queues interleave differently - match by kernel name)
+acc = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+for n, f in fetch:
+    a = acc[n]; a[0] += 1; a[1] += f
+for n, w in write:
+    a = acc[n]; a[2] += 1; a[3] += w
+bad = {n: (a[0], a[2]) for n, a in acc.items() if a[0] != a[2]}
+if bad:
+    sys.exit(f"pmc_traffic: the two passes of {tag} did not launch the same step: {bad}")
+acc = {n: [a[0], a[1], a[3]] for n, a in acc.items()}
 res, total = {}, 0.0
 for n, (k, f, w) in acc.items():
     # units: KiB.  gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (guide, HBM section)
