@@ -77,14 +77,21 @@ def traffic_profile(config_name, dtype):
     return d if "_step" in d else None
 
 
-def pmc_traffic(config_name, dtype, N):
+def x3r_session(cfg, B, dtype):
+    """engine.hip plan_model, ModelPlan::x3r: a bf16x3 session on a graph beyond the fused two-hop kernels (N > 352) runs the bf16 mode's
+    data flow with hi/lo operand pairs - three MFMAs per product on the bf16-resident GEMM - when the hoisted forward and backward take
+    the shape (H % 32 == 0, B x input channels % 8 == 0)."""
+    return dtype == "bf16x3" and cfg["N"] > 352 and cfg["H"] % 32 == 0 and (cfg["H"] + cfg["D"]) % 32 == 0 and B % 8 == 0
+
+
+def pmc_traffic(config_name, dtype, N, x3r=False):
     """Fabric-side bytes per launch of the dominant kernel (the forward propagation) in a steady-state step:
     FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md."""
     d = traffic_profile(config_name, dtype)
     if d is None:
         return None
     # (tools/pmc_traffic.sh folds the tile parameters of the tuned GEMMs away: family<*, operand forms, ROLE>)
-    if dtype == "bf16":
+    if dtype == "bf16" or x3r:
         keys = ("gemm_bf16*<*, true, 1>",)        # gemm_bf16(_pp)_kernel<..., BTR = true, ROLE = 1>
     elif N <= 352 and dtype == "bf16x3":
         keys = ("prop2_fwd_kernel",)              # fused two-hop kernels (prop_small.h)
@@ -129,7 +136,10 @@ def propagation_alg_bytes(cfg, B, dtype):
     N, H, D, K = cfg["N"], cfg["H"], cfg["D"], 3
     out = []
     for C, Hs in ((1 + H, H), (2 + H + D, H + D)):
-        if dtype == "bf16" and Hs in (32, 64, 128):
+        if x3r_session(cfg, B, dtype):
+            # hi/lo operand pairs: stacked adjacency and the packed state block twice (hi + lo images), fp32 planes out
+            out.append(2 * (2 * (K - 1) * N * N * 2 + N * B * Hs * 2) + 2 * (K - 1) * N * B * Hs * 4)
+        elif dtype == "bf16" and Hs in (32, 64, 128):
             # hoisted bf16 mode: stacked bf16 adjacency (2(K-1) blocks), the bf16 state block (Hs channels;
             # the input channels are propagated once per stack), bf16-resident output planes
             out.append(2 * (K - 1) * N * N * 2 + N * B * Hs * 2 + 2 * (K - 1) * N * B * Hs * 2)
@@ -141,8 +151,8 @@ def propagation_alg_bytes(cfg, B, dtype):
         else:                     # fp32 storage: both supports, input plane, 2(K-1) output planes
             out.append(2 * N * N * 4 + N * B * C * 4 + 2 * (K - 1) * N * B * C * 4)
     per_call = sum(out) / 2.0
-    # bf16x3 at N > 352 launches one hop at a time (2 launches per AGCN call): half the bytes per launch
-    hops_per_launch = 1 if (dtype != "bf16" and N > 352) else 2
+    # the tiled path at N > 352 (f32; bf16x3 shapes the resident path does not take) launches one hop at a time: half the bytes per launch
+    hops_per_launch = 1 if (dtype != "bf16" and N > 352 and not x3r_session(cfg, B, dtype)) else 2
     return per_call * hops_per_launch / 2.0
 
 
@@ -240,9 +250,11 @@ def self_launch(args):
     return subprocess.call(launch_cmd(args.gpus, port, sys.argv[1:]), env=launch_env())
 
 
-def prop_kernel_name(cfg, dtype):
+def prop_kernel_name(cfg, dtype, B=8):
     small = cfg["N"] <= 352 and dtype == "bf16x3"
     return ("mcrn::gemm_bf16(_pp)_kernel<BM,BN,..,BTR=true,ROLE=1> (all Chebyshev terms of both supports, one product)" if dtype == "bf16" else
+            "mcrn::gemm_bf16(_pp)_kernel<BM,BN,..,BTR=true,ROLE=1> with hi/lo operand pairs (nterm = 3: all Chebyshev terms of both supports, "
+            "one product, three MFMAs per product)" if x3r_session(cfg, B, dtype) else
             "mcrn::prop2_fwd_kernel<NF,CT> (both Chebyshev hops fused)" if small else
             "mcrn::gemm_%s_kernel<..., ROLE=1>" % ("bf16x3" if dtype == "bf16x3" else "f32"))
 
@@ -305,12 +317,12 @@ def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
     ridge = PEAK[dtype] / HBM_PEAK
     frac_mfma, frac_hbm = alg_flops / launch_s / PEAK[dtype], alg_bytes / launch_s / HBM_PEAK
     bound = "mfma" if ai >= ridge else "hbm"
-    return {"bound": bound, "kernel": prop_kernel_name(cfg, dtype) + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
+    return {"bound": bound, "kernel": prop_kernel_name(cfg, dtype, B) + " (K-hop propagation S x Z, model/MegaCRN.py:25)",
             "achieved": round(alg_flops / launch_s / 1e12, 3) if bound == "mfma" else round(alg_bytes / launch_s / 1e9, 1),
             "peak": round(PEAK[dtype] / 1e12, 1) if bound == "mfma" else HBM_PEAK / 1e9,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 5),
-            "traffic": pmc_traffic(config_name, dtype, cfg["N"]),
+            "traffic": pmc_traffic(config_name, dtype, cfg["N"], x3r_session(cfg, B, dtype)),
             "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
             "frac_of_mfma_peak": round(frac_mfma, 5), "frac_of_hbm_peak": round(frac_hbm, 5),
             "achieved_tflops": round(alg_flops / launch_s / 1e12, 3), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 1),

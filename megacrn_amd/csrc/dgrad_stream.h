@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
     // dealt round-robin over the XCDs every one of them fetched the rows through the fabric: 79 MB per launch for 25 MB of work).
     const int xcd = (int)(blockIdx.x & 7);
     const long long slot = blockIdx.x >> 3;
-    const int part = (int)(slot % p.parts);
-    const long long rg = (slot / p.parts) * 8 + xcd;
+    // (the quotient and remainder of a run-time divisor come out of VALU code: back to SGPRs once, here)
+    const int part = __builtin_amdgcn_readfirstlane((int)(slot % p.parts));
+    const long long rg = (long long)__builtin_amdgcn_readfirstlane((int)(slot / p.parts)) * 8 + xcd;
     if (rg * 128 >= p.R) return;                                      // (grid padded to 8 row groups per round; uniform over the workgroup)
     const long long rf = rg * 4 + wave;
     const bool live = rf * 32 < p.R;                                  // whole wave beyond the last row: helps staging only
@@ -168,9 +169,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const int dr = (v & 3) + 8 * (v >> 2);
-                        unsigned u = __float_as_uint(acc[v] + acx[v]);
+                        const float val = acc[v] + acx[v];
+                        unsigned u = __float_as_uint(val);
                         u += 0x7FFFu + ((u >> 16) & 1u);
-                        if (rows_in || r0 + dr < p.R) c[dr * hh] = (unsigned short)(u >> 16);
+                        if (rows_in || r0 + dr < p.R) {
+                            c[dr * hh] = (unsigned short)(u >> 16);
+                            if (p.dPb_lo > 0) {                      // hi/lo operand pairs (gemm_bf16.h, nterm = 3): the residual as a second bf16
+                                unsigned ul = __float_as_uint(val - __uint_as_float(u & 0xFFFF0000u));
+                                ul += 0x7FFFu + ((ul >> 16) & 1u);
+                                c[p.dPb_lo + dr * hh] = (unsigned short)(ul >> 16);
+                            }
+                        }
                     }
                 } else if (cc < p.H + p.d && p.dPin) {
                     // row r = n * B + b -> element (n, in_col0 + b * d + j): one division, then the 28 row steps by carry
@@ -181,9 +190,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
                         if ((dr & 4) == 0) {
                             const int v = (dr & 3) + 4 * (dr >> 3);
                             if (rows_in || r0 + dr < p.R) {
-                                unsigned u = __float_as_uint(acc[v] + acx[v]);
+                                const float val = acc[v] + acx[v];
+                                unsigned u = __float_as_uint(val);
                                 u += 0x7FFFu + ((u >> 16) & 1u);
                                 c[(long long)nn * p.kin + bb * p.d] = (unsigned short)(u >> 16);
+                                if (p.dPin_lo > 0) {
+                                    unsigned ul = __float_as_uint(val - __uint_as_float(u & 0xFFFF0000u));
+                                    ul += 0x7FFFu + ((ul >> 16) & 1u);
+                                    c[p.dPin_lo + (long long)nn * p.kin + bb * p.d] = (unsigned short)(ul >> 16);
+                                }
                             }
                         }
                         if (++bb == (unsigned)p.B) { bb = 0; ++nn; }

@@ -36,6 +36,8 @@ int g_debug = 0;                        // ablation bits of the measurement buil
 static int g_precision = MCRN_BF16X3;   // contraction arithmetic of every GEMM launch (MCRN_F32 or MCRN_BF16X3)
 static bool g_prop_bf16 = false;        // MCRN_BF16: propagation / its transpose / adjacency gradient on bf16-resident operands
                                         // (gemm_bf16.h); every other contraction keeps the bf16x3 arithmetic
+static bool g_x3r = false;              // ... with hi/lo operand PAIRS and three MFMAs per product (gemm_bf16.h, nterm = 3): what a bf16x3 session
+                                        // runs on the large graphs since round 5 - the bf16 mode's data flow in the 1e-4 arithmetic (ModelPlan::x3r)
 static char g_err[512] = "";
 static int g_launches = 0;
 
@@ -286,6 +288,12 @@ static void side_reset() {
 }
 // The library keeps ONE process-wide arithmetic mode, helper stream and tile cache: one device and one host
 // thread per process (the launch model of bench.py / megacrn_amd.train: one process per GPU).
+// a bf16x3 session planned onto the bf16-resident data flow (ModelPlan::x3r): the product sites switch on g_prop_bf16 / g_x3r
+struct X3rScope {
+    bool saved_bf, saved_x3, on;
+    explicit X3rScope(bool enable) : saved_bf(g_prop_bf16), saved_x3(g_x3r), on(enable) { if (on) { g_prop_bf16 = true; g_x3r = true; } }
+    ~X3rScope() { if (on) { g_prop_bf16 = saved_bf; g_x3r = saved_x3; } }
+};
 struct PrecisionScope {
     int saved; bool saved_bf;
     explicit PrecisionScope(int p) : saved(g_precision), saved_bf(g_prop_bf16) {
@@ -317,6 +325,7 @@ struct Shp {   // one AGCN / cell geometry
     long long PSbh;               // Kp * ldh: one packed bf16 [Kp][B*H] matrix
     bool lite;                    // ... and it writes bf16-RESIDENT planes [nb][N*B][H] that the streaming weight pool
                                   // (wp_stream.h) and the weight gradient read directly: no fp32 plane round trip
+    long long lo_x0b, lo_x0c, lo_dPb, lo_dPin;   // x3r: element offsets of the lo images behind this stack's bf16 operands (0 otherwise)
     bool hoist_fwd;               // bf16x3, fused two-hop path, H % 64 == 0 (decoder of the small graphs): forward steps whose input channels
                                   // are known before the stack starts propagate the B*H state columns only (128 units = one round of 256
                                   // workgroups at METR-LA instead of 88 units of 96 columns: 22.4 -> 17.7 us); their input / pad channels
@@ -340,6 +349,7 @@ static Shp mk_shape(int B, int N, int d, int H, int K, bool bf16_rows = false) {
     s.ldh = (long long)B * H;
     s.PSbh = (long long)s.Kp * s.ldh;
     s.hoist_fwd = false; s.state_only = false; s.hoist_bwd = false;
+    s.lo_x0b = s.lo_x0c = s.lo_dPb = s.lo_dPin = 0;
     s.lite = s.hoist && wp_stream_ok(H, d, 2 * (K - 1), H) && wp_stream_ok(H, d, 2 * (K - 1), 2 * H);
     return s;
 }
@@ -365,6 +375,7 @@ struct Sup {   // the two supports, their transposes, and the slabbed gradient a
     const uint16_t* STstk = nullptr;
     int Kp = 0, nb = 0;
     float *mu = nullptr, *mu_part = nullptr;    // column sums of a plane over its nodes (+ partials)
+    long long lo_Sstk = 0, lo_STstk = 0, lo_xin_b = 0;   // x3r: offsets of the lo images behind Sstk / STstk / the hoisted input operand
 };
 static int nslab_S(int N) {
     // N <= 256: one ds_small workgroup per slab; its slab read + write is ~9 us whatever its K range, so fewer,
@@ -432,7 +443,8 @@ static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
 static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, hipStream_t st, int prof_role = -1) {
     ++g_launches;
     if (nsplit < 1) nsplit = 1;
-    const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len, nsplit, role};
+    const int nterm_ = p.nterm > 1 ? p.nterm : 1;
+    const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len * nterm_, nsplit, role};
     int cfg = g_force_cfg_bf16;
     if (cfg < 0 || cfg >= NCFG_BF16) {
         auto it = g_tuned_bf16.find(key);
@@ -490,7 +502,7 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
     p.ev0 = p.ev1 = nullptr;
     if (prof) {
         if (!ext) CK(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st));
-        const double ex = 2.0 * p.M * (double)p.N * (double)p.nseg * p.seg_len;
+        const double ex = 2.0 * p.M * (double)p.N * (double)p.nseg * p.seg_len * nterm_;
         g_prof.exec_flops += ex;
         g_prof.alg_flops += alg > 0 ? alg : ex;
         ++g_prof.n;
@@ -503,10 +515,15 @@ static Bf16GemmP bgp(const Sup& u) {
     p.alpha = 1.f; p.nsplit = 1; p.xcd = 1;
     return p;
 }
+// hi/lo operand pairs of a bf16x3 session on the resident path (g_x3r): A_hi B_hi + A_hi B_lo + A_lo B_hi in one K loop
+static inline void x3_terms(Bf16GemmP& p, long long a_lo, long long b_lo) {
+    if (g_x3r) { p.nterm = 3; p.a_lo = a_lo; p.b_lo = b_lo; }
+}
+static inline int x3_nterm() { return g_x3r ? 3 : 1; }
 // plane (N x ld fp32) -> bf16 copy (propagation operand) and node-centred bf16 copy (adjacency-gradient operand)
 static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st);
 static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
-                          int nvalid, long long src_ps, long long dst_ps, long long mu_stride);
+                          int nvalid, long long src_ps, long long dst_ps, long long mu_stride, long long lo = 0);
 
 // MCRN_BF16 forward propagation: ALL Chebyshev terms of both supports as ONE product
 //   [S1; T2(S1); S2; T2(S2)] (nb*N x N, bf16)  x  plane 0 (N x B*Cp, bf16)  ->  planes 1 .. nb (fp32)
@@ -515,13 +532,14 @@ struct PackX {                    // optional arguments of k_pack_cols_bf16 (see
     int ny = 1; long long src_y = 0, dst_y = 0;                    // planes (grid.y), strides: floats / uint4
     const float* mu = nullptr; long long mu_t = 0, mu_y = 0; float inv_rows = 0.f;
     int coff = 0, ncw = 0, tmul = 1, toff = 0, rows = -1;          // rows: destination rows (default Kp, zero beyond N)
+    long long lo = 0;                                              // x3r: elements between the hi image and the lo image it also writes
 };
 static int pack_cols_bf16(const float* src, long long src_t, const Shp& s, int col0, int w, int T, int ldo, uint16_t* dst, hipStream_t st,
                           const PackX& x = PackX()) {
     const int rows = x.rows < 0 ? s.Kp : x.rows;
     const long long n = (long long)rows * ((x.ncw > 0 ? x.ncw : ldo) / 8);
     LAUNCH(k_pack_cols_bf16, dim3(cdiv(n, 256), x.ny), dim3(256), 0, st, src, src_t, s.N, s.ld, s.Cp, col0, w, s.B, T, rows, ldo,
-           reinterpret_cast<uint4*>(dst), x.src_y, x.dst_y, x.mu, x.mu_t, x.mu_y, x.inv_rows, x.coff, x.ncw, x.tmul, x.toff);
+           reinterpret_cast<uint4*>(dst), x.src_y, x.dst_y, x.mu, x.mu_t, x.mu_y, x.inv_rows, x.coff, x.ncw, x.tmul, x.toff, x.lo / 8);
     return 0;
 }
 static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, uint16_t* x0c, hipStream_t st,
@@ -541,9 +559,11 @@ static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, ui
     if (s.hoist) {
         // only the state channels change from step to step: B = their packed bf16 copy (N x B*H), the result lands in the
         // h-channel block of every (node, sample) row of planes 1 .. nb; the input-channel blocks were filled by hoist_inputs
-        CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st));
+        PackX xs_; xs_.lo = s.lo_x0b;
+        CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st, xs_));
         p.B = x0b; p.ldb = s.ldh; p.N = (int)s.ldh;
         p.cn_inner = s.H; p.cn_hi = s.Cp;
+        x3_terms(p, u.lo_Sstk, s.lo_x0b);
         return bf16_gemm(p, true, 1, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.H, st);
     }
     CKI(plane_to_bf16(s, u, Z, x0b, x0c, st));
@@ -559,8 +579,10 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     if (!s.hoist || w <= 0 || T <= 0) return 0;
     const int ncols = T * s.B * w;
     const int ncp = ncols < 8 ? 8 : (ncols + 7) & ~7;
-    CKI(pack_cols_bf16(Z, s.ZT, s, col0, w, T, ncp, xin_b, st));
+    PackX xs_; xs_.lo = u.lo_xin_b;
+    CKI(pack_cols_bf16(Z, s.ZT, s, col0, w, T, ncp, xin_b, st, xs_));
     Bf16GemmP p = bgp(u);
+    x3_terms(p, u.lo_Sstk, u.lo_xin_b);
     p.A = u.Sstk; p.am = rm_plain(u.Kp); p.M = u.nb * s.N;
     p.B = xin_b; p.ldb = ncp; p.N = ncp;
     p.nseg = 1; p.seg_len = s.N;
@@ -571,7 +593,7 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     nsplit = nsplit < 1 ? 1 : (nsplit > HOIST_MAX_SPLIT ? HOIST_MAX_SPLIT : nsplit);
     // splits the launcher really makes (bf16_split_plan) for a K tile of 64 and of 32: the consumer below must know the count
     // whatever tile configuration the tuner picks, so a request that the two depths would round differently is not split
-    auto eff = [&](int bk) { const int kt = cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk) { const int kt = x3_nterm() * cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
     if (eff(64) != eff(32) || bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;    // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64);
     p.slab = (long long)p.M * ncp;
@@ -619,7 +641,7 @@ static const int PROPT_MAX_X = 3;                       // extra partial planes 
 // and of 32: the consumers of the partial planes must know the count whatever tile the tuner picks, so a request is only
 // usable when both depths round it the same way and to itself (-1 otherwise).  want = 2 is exact for every K >= 2 tiles.
 static int bf16_eff_splits(int nseg, int seg_len, int want) {
-    auto eff = [&](int bk) { const int kt = nseg * cdiv(seg_len, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk) { const int kt = x3_nterm() * nseg * cdiv(seg_len, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
     return eff(64) == eff(32) && eff(64) == want ? want : -1;
 }
 struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
@@ -639,6 +661,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.cin_pre = 1;                               // the K loop starts FROM plane 0: no read-modify-write epilogue (gemm_bf16.h, bf16_acc_preload;
                                                  // 58.0 -> 55.8 us per launch, EXPY-TKY step +0.7 %: profiles/r5/experiments.md section 2)
     if (hoisted) { p.ldb = s.ldh; p.N = (int)s.ldh; p.b_seg = s.PSbh; p.cn_inner = s.H; p.cn_hi = s.Cp; }
+    x3_terms(p, u.lo_STstk, s.lo_dPb);
     int nsplit = 1;
     const int split_env = 0;                                 // K splits: tuned (2 .. 4) with the tile
     const double alg = (double)u.nb * 2.0 * (double)s.N * s.N * (double)s.B * (hoisted ? s.H : s.C);
@@ -693,16 +716,18 @@ static int ds_bf16_h(const Shp& s, const Sup& u, const uint16_t* dPbh_all, const
     p.nseg = ncalls; p.seg_len = (int)s.ldh; p.a_seg = (long long)u.nb * s.PSbh; p.b_seg = s.PSbh;
     p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS);
     if (accumulate) { p.Cin = dA; p.beta = 1.f; }
+    x3_terms(p, s.lo_dPb, s.lo_x0c);
     return bf16_gemm(p, false, 1, ROLE_DS, (double)ncalls * u.nb * 2.0 * (double)s.N * s.N * (double)s.B * s.H, st);
 }
 // ... plus the input channels of every call as ONE narrow product:  dA[b] += dPin[b] (N x kcols) x xin_c^T (N x kcols)
 static int ds_bf16_in(const Shp& s, const Sup& u, const uint16_t* dPin, const uint16_t* xin_c, long long kin, int kcols, float* dA,
-                      long long ldS, hipStream_t st) {
+                      long long ldS, hipStream_t st, long long lo_xin_c = 0) {
     Bf16GemmP p = bgp(u);
     p.A = dPin; p.am = rm_plain(kin); p.M = u.nb * s.N;
     p.B = xin_c; p.bm = rm_plain(kin); p.N = s.N;
     p.nseg = 1; p.seg_len = kcols;
     p.C = dA; p.cm = rm_two(s.N, (long long)s.N * ldS, ldS); p.Cin = dA; p.beta = 1.f;
+    x3_terms(p, s.lo_dPin, lo_xin_c);
     return bf16_gemm(p, false, 1, ROLE_DS, (double)u.nb * 2.0 * (double)s.N * s.N * (double)kcols, st);
 }
 // hoisted backward, a decoder cell whose go symbol was the projection of the previous step (not teacher-forced): the input
@@ -717,13 +742,14 @@ static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long l
     p.B = dPin + (long long)call0 * bw; p.ldb = kin; p.N = 2 * bw;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = (long long)s.N * kin;
     p.C = tmp; p.cm = rm_plain(2 * bw);
+    x3_terms(p, u.lo_STstk, s.lo_dPin);
     // N x 2*B*d output (8 tiles of 256 x 128 at N = 1843) over K = nb*N: split K so that the launch fills the chip (88 us unsplit)
     const long long tiles = (long long)cdiv(p.M, 256) * cdiv(p.N, 128);
     int nsplit = (int)((240 + tiles / 2) / tiles);
     nsplit = nsplit < 1 ? 1 : (nsplit > GO_MAX_SPLIT ? GO_MAX_SPLIT : nsplit);
     // splits the launcher really makes for a K tile of 64 and of 32 (bf16_split_plan): the consumer below must know the count
     // whatever tile the tuner picks, so the request is lowered until both depths round it the same way
-    auto eff = [&](int bk, int want) { const int kt = u.nb * cdiv(s.N, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk, int want) { const int kt = x3_nterm() * u.nb * cdiv(s.N, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
     while (nsplit > 1 && eff(64, nsplit) != eff(32, nsplit)) --nsplit;
     if (bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;                             // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64, nsplit);
@@ -880,6 +906,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         q.dPb = nullptr; q.PSb = 0; q.H = 0; q.d = s.d; q.B = s.B; q.dPin = nullptr; q.kin = 0; q.in_plane = 0; q.in_col0 = 0;
         if (g_prop_bf16 && u.STstk && dPb && dPin) {            // hoisted backward: packed state channels + the input operand
             q.dPb = dPb; q.PSb = s.PSbh; q.H = s.H; q.dPin = dPin; q.kin = kin; q.in_plane = (long long)s.N * kin; q.in_col0 = in_col0;
+            q.dPb_lo = s.lo_dPb; q.dPin_lo = s.lo_dPin;
             dgrad_wrote_bf16 = true;
         } else if (g_prop_bf16 && u.STstk && dPb && s.ldp == s.ld) {   // bf16 plane rows then coincide with the fp32 rows: write them here
             q.dPb = dPb; q.PSb = s.PSb; dgrad_wrote_bf16 = true;
@@ -897,9 +924,10 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     }
     if (g_prop_bf16 && u.STstk && dPb && dPin) {
         if (!dgrad_wrote_bf16) {   // tiled d-grad (O > 128) wrote fp32 planes: pack the state channels and the input channels from them
-            PackX xh; xh.ny = u.nb; xh.src_y = s.PS; xh.dst_y = s.PSbh / 8;
+            PackX xh; xh.ny = u.nb; xh.src_y = s.PS; xh.dst_y = s.PSbh / 8; xh.lo = s.lo_dPb;
             CKI(pack_cols_bf16(dP + s.PS, 0, s, 0, s.H, 1, (int)s.ldh, dPb, st, xh));
             PackX xi; xi.ny = u.nb; xi.src_y = s.PS; xi.dst_y = (long long)s.N * kin / 8; xi.coff = in_col0; xi.ncw = (s.B * s.d + 7) & ~7; xi.rows = s.N;
+            xi.lo = s.lo_dPin;
             CKI(pack_cols_bf16(dP + s.PS, 0, s, s.H, s.d, 1, (int)kin, dPin, st, xi));
         }
         return prop_bwd_bf16(s, u, dP, dPb, dT, used_dT, st, true);
@@ -1129,11 +1157,11 @@ static int colsum(const float* X, long long ld, long long rows, int C, float* pa
 static size_t colsum_part_floats(long long rows, int C, int chunk = COLSUM_CHUNK) { return (size_t)cdiv(rows, chunk) * C; }
 static const int MU_CHUNK = 64;       // rows per partial of the node-mean of a plane (wide grid: N / 64 x ld / 64 workgroups)
 static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
-                          int nvalid = -1, long long src_ps = -1, long long dst_ps = -1, long long mu_stride = 0) {
+                          int nvalid = -1, long long src_ps = -1, long long dst_ps = -1, long long mu_stride = 0, long long lo) {
     const long long n = (long long)np * s.Kp * (s.ldp / 8);
     LAUNCH(k_plane_to_bf16, dim3(cdiv(n, 256)), dim3(256), 0, st, X, src_ps < 0 ? s.PS : src_ps, s.N, (int)s.ld,
            nvalid < 0 ? (int)s.ld : nvalid, s.Kp, (int)s.ldp, np, reinterpret_cast<uint4*>(xb), reinterpret_cast<uint4*>(xc), mu,
-           1.f / (float)s.N, mu_stride, (dst_ps < 0 ? s.PSb : dst_ps) / 8);
+           1.f / (float)s.N, mu_stride, (dst_ps < 0 ? s.PSb : dst_ps) / 8, lo / 8);
     return 0;
 }
 // forward: only the plain bf16 copy (operand of the propagation); the centred copies are made in the backward pass
@@ -1482,6 +1510,8 @@ struct ModelPlan {
     float *part, *part2, *part3;
     // MCRN_BF16: stacked bf16 adjacency and its transpose, T2 matrices, per-call bf16 operands, adjacency-gradient blocks
     bool bf16;
+    bool x3r;                         // a bf16x3 session on the bf16-resident data flow: hi/lo operand pairs, three MFMAs per product (g_x3r)
+    long long lo_Sstk, lo_STstk, lo_sqb, lo_xin_b, lo_xin_c;      // ... element offsets of the lo images behind the shared operands (0 otherwise)
     int nb, Kp;
     uint16_t *Sstk, *STstk, *sqb;   // sqb: one zero-padded bf16 [Kp][Kp] matrix (S for the T2 product, dT in the backward pass)
     float *T2[2], *t2part[2], *dA, *mu, *mu_part;
@@ -1513,10 +1543,23 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     Bump b{base, 0};
     const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num, K = d->cheb_k;
     const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim;
-    P.bf16 = d->precision == MCRN_BF16;
+    // bf16x3 sessions on the large graphs (no fused two-hop kernels beyond N = 352) take the bf16 mode's data flow - stacked adjacency
+    // operands, hoisted state-channel products, one adjacency-gradient product per stack - with hi/lo operand PAIRS and three MFMAs per
+    // product (round 5, "x3r"): the same ~1e-5 arithmetic as the tiled bf16x3 GEMM it replaces there, on the LDS-DMA kernels of
+    // gemm_bf16.h.  Needs the hoisted forward and backward (H % 32 == 0, B * input channels % 8 == 0); other shapes keep the tiled path.
+    const bool x3r_try = d->precision == MCRN_BF16X3 && N > PROP2_MAX_N && K <= 3;
+    P.bf16 = d->precision == MCRN_BF16 || x3r_try;
     P.se = mk_shape(B, N, d->input_dim, H, K, P.bf16);
     P.sd = mk_shape(B, N, od + yd, Hd, K, P.bf16);
-    P.ldS = d->precision == MCRN_BF16 ? (N + 7) & ~7 : (N + 3) & ~3;
+    P.x3r = x3r_try && P.se.hoist && P.sd.hoist && (B * d->input_dim) % 8 == 0 && (B * (od + yd)) % 8 == 0;
+    if (x3r_try && !P.x3r) {
+        P.bf16 = false;
+        P.se = mk_shape(B, N, d->input_dim, H, K, false);
+        P.sd = mk_shape(B, N, od + yd, Hd, K, false);
+    }
+    if (P.x3r) P.se.lite = P.sd.lite = false;      // the propagated planes stay fp32 (bf16-resident planes would cost the 1e-4)
+    P.lo_Sstk = P.lo_STstk = P.lo_sqb = P.lo_xin_b = P.lo_xin_c = 0;
+    P.ldS = P.bf16 ? (N + 7) & ~7 : (N + 3) & ~3;
     P.nslabS = nslab_S(N);
     plan_sup(b, N, M, D, P.ldS, P.sup);
     // four-block adjacency gradient (Sup::ds4) wherever the fused two-hop chain and the output-stationary kernels take both cell shapes
@@ -1585,6 +1628,9 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.bwd_hoist = false; P.kin_e = P.kin_d = 0; P.dPin_e = P.dPin_d = P.xin_c = nullptr; P.go_tmp = nullptr;
     for (int i = 0; i < 4; ++i) P.wpimg[i] = nullptr;
     if (P.bf16) {
+        // x3r: every bf16 operand is a hi image followed by its lo image (lo offset = the hi image's size, multiples of 8 elements)
+        const size_t lm = P.x3r ? 2 : 1;
+        auto take16 = [&](size_t n, long long* lo) { n = (n + 7) & ~(size_t)7; uint16_t* q = b.take<uint16_t>(lm * n); if (lo) *lo = P.x3r ? (long long)n : 0; return q; };
         if (P.se.lite && P.sd.lite) {
             P.Pb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * N * P.se.ldh + 64);     // (+ slack: 16-byte reads of 8-byte quads)
             P.Pb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * N * P.sd.ldh + 64);
@@ -1592,38 +1638,40 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
                 P.Xp_e = b.take<float>((size_t)d->T_in * P.nb * R * 4 + 64);
                 P.Xp_d = b.take<float>((size_t)d->T_out * P.nb * R * 4 + 64);
             }
+        }
+        if ((P.se.lite && P.sd.lite) || P.x3r) {
             const int bwe = B * d->input_dim, bwd_ = B * (od + yd);
             P.bwd_hoist = (bwe % 8) == 0 && (bwd_ % 8) == 0;
             if (P.bwd_hoist) {
                 P.kin_e = ((long long)2 * d->T_in * bwe + 63) & ~63LL;
                 P.kin_d = ((long long)2 * d->T_out * bwd_ + 63) & ~63LL;
-                P.dPin_e = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_e);
-                P.dPin_d = b.take<uint16_t>((size_t)(P.nb * N + 64) * P.kin_d);
-                P.xin_c = b.take<uint16_t>((size_t)(N + 64) * (P.kin_e > P.kin_d ? P.kin_e : P.kin_d));
+                P.dPin_e = take16((size_t)(P.nb * N + 64) * P.kin_e, &P.se.lo_dPin);
+                P.dPin_d = take16((size_t)(P.nb * N + 64) * P.kin_d, &P.sd.lo_dPin);
+                P.xin_c = take16((size_t)(N + 64) * (P.kin_e > P.kin_d ? P.kin_e : P.kin_d), &P.lo_xin_c);
                 P.go_tmp = b.take<float>((size_t)GO_MAX_SPLIT * N * 2 * bwd_ + 64);
             }
         }
         {
             const long long ce = (long long)d->T_in * B * d->input_dim, cd = (long long)d->T_out * B * (od + yd);
             const size_t ncp = (size_t)(((ce > cd ? ce : cd) + 7) & ~7LL) + 8;
-            P.xin_b = b.take<uint16_t>((size_t)P.Kp * ncp);
+            P.xin_b = take16((size_t)P.Kp * ncp, &P.lo_xin_b);
             P.xin_t = b.take<float>((size_t)8 /* HOIST_MAX_SPLIT */ * P.nb * N * ncp);
         }
-        P.Sstk = b.take<uint16_t>((size_t)P.nb * N * P.Kp);
-        P.STstk = b.take<uint16_t>((size_t)N * P.nb * P.Kp);
-        P.sqb = b.take<uint16_t>((size_t)P.Kp * P.Kp);
+        P.Sstk = take16((size_t)P.nb * N * P.Kp, &P.lo_Sstk);
+        P.STstk = take16((size_t)N * P.nb * P.Kp, &P.lo_STstk);
+        P.sqb = take16((size_t)P.Kp * P.Kp, &P.lo_sqb);
         for (int i = 0; i < 2; ++i) P.T2[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;
         for (int i = 0; i < 2; ++i) P.t2part[i] = K == 3 ? b.take<float>((size_t)N * P.ldS) : nullptr;   // second K split of the N^3 products
         P.dA = b.take<float>((size_t)P.nb * N * P.ldS);
         const long long ldm = P.se.ld > P.sd.ld ? P.se.ld : P.sd.ld;
         P.mu = b.take<float>((size_t)2 * (d->T_in > d->T_out ? d->T_in : d->T_out) * ldm);
         P.mu_part = b.take<float>(colsum_part_floats(N, (int)ldm, MU_CHUNK) + 1024);
-        P.x0b_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
-        P.x0c_e = b.take<uint16_t>((size_t)2 * d->T_in * P.se.PSb);
-        P.x0b_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
-        P.x0c_d = b.take<uint16_t>((size_t)2 * d->T_out * P.sd.PSb);
-        P.dPb_e = b.take<uint16_t>((size_t)2 * d->T_in * P.nb * P.se.PSb);
-        P.dPb_d = b.take<uint16_t>((size_t)2 * d->T_out * P.nb * P.sd.PSb);
+        P.x0b_e = take16((size_t)2 * d->T_in * P.se.PSb, &P.se.lo_x0b);
+        P.x0c_e = take16((size_t)2 * d->T_in * P.se.PSb, &P.se.lo_x0c);
+        P.x0b_d = take16((size_t)2 * d->T_out * P.sd.PSb, &P.sd.lo_x0b);
+        P.x0c_d = take16((size_t)2 * d->T_out * P.sd.PSb, &P.sd.lo_x0c);
+        P.dPb_e = take16((size_t)2 * d->T_in * P.nb * P.se.PSb, &P.se.lo_dPb);
+        P.dPb_d = take16((size_t)2 * d->T_out * P.nb * P.sd.PSb, &P.sd.lo_dPb);
     }
     P.xin_f = nullptr;
     {
@@ -1670,6 +1718,7 @@ static Sup model_sup(const ModelPlan& P, int N) {
     u.sup_stride = (long long)P.nslabS * u.slab;
     if (P.ds4) { u.ds4 = true; u.slab = (long long)4 * N * P.ldS; u.sup_stride = 0; }   // one slab = the four blocks side by side
     u.Sstk = P.Sstk; u.STstk = P.STstk; u.Kp = P.Kp; u.nb = P.nb; u.mu = P.mu; u.mu_part = P.mu_part;
+    u.lo_Sstk = P.lo_Sstk; u.lo_STstk = P.lo_STstk; u.lo_xin_b = P.lo_xin_b;
     return u;
 }
 
@@ -1685,8 +1734,8 @@ static int build_stacks(const ModelPlan& P, const Sup& u, int N, int K, hipStrea
     const int nb = P.nb;
     const dim3 g(cdiv(P.Kp, 32), cdiv(N, 32));
     auto put = [&](const float* M_, int blk) -> int {
-        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 0, P.Sstk, (long long)P.Kp, (long long)blk * N, 0LL);
-        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 1, P.STstk, (long long)nb * P.Kp, 0LL, (long long)blk * P.Kp);
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 0, P.Sstk, (long long)P.Kp, (long long)blk * N, 0LL, P.lo_Sstk);
+        LAUNCH(k_stack_build, g, dim3(256), 0, st, M_, P.ldS, N, P.Kp, 1, P.STstk, (long long)nb * P.Kp, 0LL, (long long)blk * P.Kp, P.lo_STstk);
         return 0;
     };
     for (int sidx = 0; sidx < 2; ++sidx) {
@@ -1696,11 +1745,12 @@ static int build_stacks(const ModelPlan& P, const Sup& u, int N, int K, hipStrea
         if (K == 3) {
             // S as a zero-padded [Kp][Kp] bf16 matrix: the [k][n] operand must be finite for k up to Kp
             Shp t; t.N = N; t.ld = P.ldS; t.PS = (long long)N * P.ldS; t.Kp = P.Kp; t.ldp = P.Kp; t.PSb = (long long)P.Kp * P.Kp;
-            CKI(planes_to_bf16(t, S, 1, P.sqb, nullptr, nullptr, st, N));
+            CKI(planes_to_bf16(t, S, 1, P.sqb, nullptr, nullptr, st, N, -1, -1, 0, P.lo_sqb));
             Bf16GemmP q = bgp(u);
             q.A = P.sqb; q.am = rm_plain(P.Kp); q.M = N;
             q.B = P.sqb; q.ldb = P.Kp; q.N = (N + 7) & ~7;        // columns N .. are zero padding
             q.nseg = 1; q.seg_len = N;
+            x3_terms(q, P.lo_sqb, P.lo_sqb);
             q.C = P.T2[sidx]; q.cm = rm_plain(P.ldS); q.alpha = 2.f;
             // N x N output = 120 tiles of 256 x 128 at N = 1843 (half a chip, 40 - 46 us per product in round 3): K is split in
             // two, the second half lands in a scratch matrix that the "- I" pass folds in
@@ -1729,7 +1779,7 @@ static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream
         uint16_t* dTb = P.sqb;              // dT as a zero-padded bf16 [Kp][Kp] matrix (rows K-contiguous / [k][n])
         {
             Shp t; t.N = N; t.ld = P.ldS; t.PS = (long long)N * P.ldS; t.Kp = P.Kp; t.ldp = P.Kp; t.PSb = (long long)P.Kp * P.Kp;
-            CKI(planes_to_bf16(t, dT, 1, dTb, nullptr, nullptr, st, N));
+            CKI(planes_to_bf16(t, dT, 1, dTb, nullptr, nullptr, st, N, -1, -1, 0, P.lo_sqb));
         }
         const uint16_t* Sb = P.Sstk + (long long)(2 * sidx) * N * P.Kp;          // S rows
         const uint16_t* STb = P.STstk + (long long)(2 * sidx) * P.Kp;            // S^T rows (row stride nb*Kp)
@@ -1740,6 +1790,7 @@ static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream
             q.B = Sb; q.bm = rm_plain(P.Kp); q.N = N;
             q.nseg = 1; q.seg_len = N;
             q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
+            x3_terms(q, P.lo_sqb, P.lo_Sstk);
             if (ns == 2) { q.slab = P.t2part[0] - dS; q.cin_first_only = 1; }
             CKI(bf16_gemm(q, false, ns, ROLE_MISC, 0, st));
         }
@@ -1749,6 +1800,7 @@ static int t2_backward(const ModelPlan& P, const Sup& u, int N, int K, hipStream
             q.B = dTb; q.ldb = P.Kp; q.N = (N + 7) & ~7;
             q.nseg = 1; q.seg_len = N;
             q.C = dS; q.Cin = dS; q.cm = rm_plain(P.ldS); q.alpha = 2.f; q.beta = 1.f;
+            x3_terms(q, P.lo_STstk, P.lo_sqb);
             if (ns == 2) { q.slab = P.t2part[1] - dS; q.cin_first_only = 1; }
             CKI(bf16_gemm(q, true, ns, ROLE_MISC, 0, st));
         }
@@ -1853,6 +1905,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                          float* query, float* pos, float* neg, hipStream_t st) {
     ModelPlan P;
     plan_model(d, ws, P);
+    X3rScope x3scope(P.x3r);
     const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num;
     const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim, din = d->input_dim;
     const int Ti = d->T_in, To = d->T_out;
@@ -1989,6 +2042,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
                           const float* d_neg, char* ws, const mcrn_grads_t* g, hipStream_t st) {
     ModelPlan P;
     plan_model(d, ws, P);
+    X3rScope x3scope(P.x3r);
     const int B = d->B, N = d->N, H = d->H, D = d->mem_dim, M = d->mem_num;
     const int Hd = H + D, od = d->output_dim, yd = d->ycov_dim;
     const int Ti = d->T_in, To = d->T_out;
@@ -2007,11 +2061,15 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             const long long np_ = (long long)2 * (e_ ? To : Ti) * P.nb, per = (long long)(s_.Kp - N) * (ldx / 8);
             LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(e_ ? P.dPb_d : P.dPb_e),
                    ps_ / 8, N, s_.Kp, (int)(ldx / 8), np_);
+            if (s_.lo_dPb > 0)     // (x3r: the lo images too)
+                LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>((e_ ? P.dPb_d : P.dPb_e) + s_.lo_dPb),
+                       ps_ / 8, N, s_.Kp, (int)(ldx / 8), np_);
         }
     }
-    if (bh) {   // K padding of the input operands (columns beyond the calls' data) must be zero
-        CK(hipMemsetAsync(P.dPin_e, 0, (size_t)(P.nb * N + 64) * P.kin_e * sizeof(uint16_t), st));
-        CK(hipMemsetAsync(P.dPin_d, 0, (size_t)(P.nb * N + 64) * P.kin_d * sizeof(uint16_t), st));
+    if (bh) {   // K padding of the input operands (columns beyond the calls' data) must be zero (x3r: hi and lo image, contiguous)
+        const size_t lm = P.x3r ? 2 : 1;
+        CK(hipMemsetAsync(P.dPin_e, 0, lm * (size_t)(se.lo_dPin > 0 ? se.lo_dPin : (long long)(P.nb * N + 64) * P.kin_e) * sizeof(uint16_t), st));
+        CK(hipMemsetAsync(P.dPin_d, 0, lm * (size_t)(sd.lo_dPin > 0 ? sd.lo_dPin : (long long)(P.nb * N + 64) * P.kin_d) * sizeof(uint16_t), st));
     }
     // ---- decoder BPTT
     const Sup& ud = u;
@@ -2113,17 +2171,20 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
             float* mu = u.mu + (long long)a * T_ * s_.ld;
             LAUNCH(k_colsum_sample, dim3(cdiv(s_.ld, 64), T_), dim3(256), 0, st, X, s_.ld, N, (int)s_.ld, nsamp, mu, s_.ZT, s_.ld);
             PackX xh; xh.ny = T_; xh.src_y = s_.ZT; xh.dst_y = 2 * s_.PSbh / 8; xh.mu = mu; xh.mu_y = s_.ld; xh.inv_rows = 1.f / (float)N;
+            xh.lo = s_.lo_x0c;
             CKI(pack_cols_bf16(X, 0, s_, 0, s_.H, 1, (int)s_.ldh, x0ch + (long long)a * s_.PSbh, st, xh));
         }
         CKI(ds_bf16_h(s_, u, e_ ? P.dPb_e : P.dPb_d, x0ch, 2 * T_, P.dA, P.ldS, e_ != 0, st));
         // input channels of every call: the centred inputs (the same for the gate and the update call of a step)
         CK(hipMemsetAsync(P.xin_c, 0, (size_t)(N + 64) * kin * sizeof(uint16_t), st));
+        if (P.lo_xin_c > 0) CK(hipMemsetAsync(P.xin_c + P.lo_xin_c, 0, (size_t)(N + 64) * kin * sizeof(uint16_t), st));
         for (int a = 0; a < 2; ++a) {
             PackX xi; xi.mu = u.mu; xi.mu_t = s_.ld; xi.inv_rows = 1.f / (float)N; xi.rows = N; xi.tmul = 2; xi.toff = a;
+            xi.lo = P.lo_xin_c;
             xi.ncw = (T_ * s_.B * s_.d + 7) & ~7;
             CKI(pack_cols_bf16(Zall, s_.ZT, s_, s_.H, s_.d, T_, (int)kin, P.xin_c, st, xi));
         }
-        CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st));
+        CKI(ds_bf16_in(s_, u, e_ ? P.dPin_e : P.dPin_d, P.xin_c, kin, 2 * T_ * s_.B * s_.d, P.dA, P.ldS, st, P.lo_xin_c));
         return 0;
     };
     CKI(wunprep(g->dec_gate_w, P.dWs[2], sd, 2 * Hd, ws_, ns1, on1 ? g->dec_gate_b : nullptr));
@@ -2333,7 +2394,7 @@ using namespace mcrn;
 extern "C" {
 
 const char* mcrn_last_error(void) { return g_err; }
-int mcrn_version(void) { return 100; }
+int mcrn_version(void) { return 105; }
 int mcrn_last_launch_count(void) { return g_launches; }
 
 int mcrn_set_gemm_cfg(int cfg) {

@@ -89,6 +89,11 @@ struct Bf16Tile {
     long long stepA_seg, stepB_seg, stepB_k;   // scalar strides (elements)
     int tps;
     int iss_seg, iss_lt;                  // K tile the next DMA will fetch
+    // hi/lo operand pairs (Bf16GemmP::nterm == 3, round 5): every K segment is walked three times,
+    //   term 0: A_hi x B_hi    term 1: A_hi x B_lo    term 2: A_lo x B_hi        (lo copies a_lo / b_lo elements behind the hi ones)
+    // = the bf16x3 arithmetic of the library (fp32 operands as bf16 hi + lo, fp32 accumulate, ~1e-5) on bf16-RESIDENT operands
+    int nterm, iss_term;
+    long long a_lo, b_lo;
 
     // (Every workgroup walks its K tiles IN ORDER.  Round 5 tried a per-tile rotated start - workgroups that share an operand panel on one
     //  XCD would then not ask for the same lines at the same time - and measured 20 - 25 % SLOWER on every product, harness and model: the
@@ -130,13 +135,19 @@ struct Bf16Tile {
             stepB_k = 1;
         }
         stepA_seg = p.a_seg; stepB_seg = p.b_seg; tps = p.tps;
-        iss_seg = kt_beg / p.tps; iss_lt = kt_beg - iss_seg * p.tps;
+        nterm = p.nterm > 1 ? p.nterm : 1; a_lo = p.a_lo; b_lo = p.b_lo;
+        const int per = nterm * p.tps;                    // K tiles of one segment (all its terms)
+        iss_seg = kt_beg / per;
+        const int r = kt_beg - iss_seg * per;
+        iss_term = r / p.tps; iss_lt = r - iss_term * p.tps;
     }
-    __device__ __forceinline__ void advance() { if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; } }
+    __device__ __forceinline__ void advance() {
+        if (++iss_lt == tps) { iss_lt = 0; if (++iss_term == nterm) { iss_term = 0; ++iss_seg; } }
+    }
     // DMA of the next K tile into LDS stage `stg`
     __device__ __forceinline__ void issue(unsigned lds_base, int stg, int wave) {
-        const uint16_t* __restrict__ Ab = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
-        const uint16_t* __restrict__ Bb = baseB + (long long)iss_seg * stepB_seg + (long long)(iss_lt * BK) * stepB_k;
+        const uint16_t* __restrict__ Ab = baseA + (long long)iss_seg * stepA_seg + (iss_term == 2 ? a_lo : 0LL) + iss_lt * BK;
+        const uint16_t* __restrict__ Bb = baseB + (long long)iss_seg * stepB_seg + (iss_term == 1 ? b_lo : 0LL) + (long long)(iss_lt * BK) * stepB_k;
         const unsigned sA = lds_base + stg * STAGE + wave * 1024;
         const unsigned sB = sA + ASLOTS * 16;
 #pragma unroll
@@ -155,8 +166,8 @@ struct Bf16Tile {
     const uint16_t *pcA, *pcB;
     unsigned pcsA, pcsB;
     __device__ __forceinline__ void issue_begin(unsigned lds_base, int stg, int wave) {
-        pcA = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
-        pcB = baseB + (long long)iss_seg * stepB_seg + (long long)(iss_lt * BK) * stepB_k;
+        pcA = baseA + (long long)iss_seg * stepA_seg + (iss_term == 2 ? a_lo : 0LL) + iss_lt * BK;
+        pcB = baseB + (long long)iss_seg * stepB_seg + (iss_term == 1 ? b_lo : 0LL) + (long long)(iss_lt * BK) * stepB_k;
         pcsA = lds_base + stg * STAGE + wave * 1024;
         pcsB = pcsA + ASLOTS * 16;
     }
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     int split;
     bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int nkt = p.nseg * p.tps;
+    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
     if (kt_beg >= kt_end) return;
@@ -557,18 +568,16 @@ struct PpLoop {
     // registers; the caller puts a barrier between the use of acc and the next run() (LDS stages are reused).
     static __device__ __forceinline__ void run(const Bf16GemmP& p, unsigned char* smem, unsigned lds_base, int tid, int wave,
                                                int m_blk, int n_blk, int kt_beg, int nt, const int (&aoff)[FM],
-                                               const int (&boff)[FN], f32x16_t (&acc)[FM][FN], bool keep_acc = false) {
+                                               const int (&boff)[FN], f32x16_t (&acc)[FM][FN]) {
         const int grp = wave / WGN;                              // waves 0-3: group 0 (upper half of the tile), 4-7: group 1
         T tl;
         tl.init(p, tid, m_blk, n_blk, kt_beg);
-        if (!keep_acc) {                                         // (keep_acc: the caller preloaded the addend, bf16_acc_preload)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-        }
 
         bf16x8_t fa[FM][KS], fb[FN][KS];
         bool first_load = true;
@@ -681,7 +690,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     int split;
     bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int nkt = p.nseg * p.tps;
+    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
     if (kt_beg >= kt_end) return;
@@ -689,9 +698,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[L::FM][L::FN];
     MCRN_CLK_PROBE(0);
-    const bool pre = p.cin_pre && split == 0;                     // workgroup-uniform
-    if (pre) bf16_acc_preload<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane);
-    L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc, pre);
+    // (no accumulator preload here: this kernel sits at the 256-VGPR limit of two waves per SIMD, and the preload's address arithmetic
+    //  pushed it into 556 bytes of scratch per lane - found in round 5 after the fact: launch_one_bf16_pp clears cin_pre)
+    L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
     MCRN_CLK_PROBE(1);
     if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
 // ---- host side ----------------------------------------------------------------------------------
 static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
     p.tps = (p.seg_len + BK - 1) / BK;
-    const int nkt = p.nseg * p.tps;
+    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nkt) nsplit = nkt;
     p.tiles_per_split = (nkt + nsplit - 1) / nsplit;
@@ -733,6 +742,7 @@ static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st
 }
 template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
 static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t st) {
+    p.cin_pre = 0;                                   // the ping-pong kernel keeps the read-modify-write epilogue (register budget, see the kernel)
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
@@ -776,6 +786,7 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
 }
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.seg_len <= 0) return hipSuccess;
+    if (p.nterm != 0 && p.nterm != 1 && p.nterm != 3) return hipErrorInvalidValue;
     // stacked outputs whose blocks are contiguous ((r / inner) * hi + (r % inner) * lo with hi == inner * lo) are plain rows
     if (p.cm.inner > 0 && p.cm.hi == (long long)p.cm.inner * p.cm.lo) p.cm = rm_plain(p.cm.lo);
     if (p.cbm.inner > 0 && p.cbm.hi == (long long)p.cbm.inner * p.cbm.lo) p.cbm = rm_plain(p.cbm.lo);

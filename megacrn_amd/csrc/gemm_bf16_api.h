@@ -28,6 +28,8 @@ struct Bf16GemmP {
     long long ldb;            // NN: elements between consecutive k rows of B
     int nseg, seg_len, tps;   // K segments, valid k per segment, k-tiles per segment = ceil(seg_len / BK) (set by the launcher)
     long long a_seg, b_seg;   // element offset between segments
+    int nterm;                // 0 / 1: plain bf16 product.  3: hi/lo operand pairs - every segment is walked as A_hi B_hi + A_hi B_lo + A_lo B_hi
+    long long a_lo, b_lo;     //        (the lo copies sit a_lo / b_lo elements behind the hi ones): the library's bf16x3 arithmetic, bf16-resident
     int M, N;                 // valid rows of A ; valid columns (NT: rows of B; NN: multiple of 8)
     float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
     const float* Cin;         // nullable

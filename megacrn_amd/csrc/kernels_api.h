@@ -157,6 +157,8 @@ struct DgradP {
     unsigned short* dPin;
     long long kin, in_plane;  // row length of dPin ; (g - 1) * in_plane = N * kin floats between the planes' row blocks
     int in_col0;
+    long long dPb_lo, dPin_lo;   // > 0 (hoisted backward, hi/lo operand pairs: gemm_bf16.h nterm = 3): the bf16 residuals are written that many
+                                 // elements behind dPb / dPin
 };
 
 

@@ -1002,6 +1002,15 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {        // finite values
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// the bf16 "lo" word of a value whose "hi" word is h: bf16(f - float(h)).  hi + lo carries 16 mantissa bits: the operand pairs of the
+// hi/lo products of gemm_bf16.h (Bf16GemmP::nterm = 3, the bf16x3 arithmetic on bf16-resident operands; round 5)
+__device__ __forceinline__ unsigned bf16_lo(float f, unsigned h) { return bf16_rne(f - __uint_as_float(h << 16)); }
+// two values -> packed hi word pair and (optionally) lo word pair
+__device__ __forceinline__ void bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned ha = bf16_rne(a), hb = bf16_rne(b);
+    hi = ha | (hb << 16);
+    lo = bf16_lo(a, ha) | (bf16_lo(b, hb) << 16);
+}
 // fp32 planes [np][N][ld] (plane stride ps_src) -> bf16 planes [np][Kp][ldp] with ZERO pad rows / columns (the operand
 // contract of gemm_bf16.h), optionally also the plane centred over its rows (nodes):
 //   dst = bf16(src) ; cen = bf16(src - colsum[col] * inv_rows).
@@ -1010,7 +1019,8 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {        // finite values
 // makes the softmax backward cancel catastrophically on large, nearly uniform supports.  8 elements per thread.
 __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src, int N, int ld, int nvalid, int Kp, int ldp,
                                 int np, uint4* __restrict__ dst, uint4* __restrict__ cen, const float* __restrict__ colsum,
-                                float inv_rows, long long colsum_stride, long long dst_ps8 /* uint4 between output planes */) {
+                                float inv_rows, long long colsum_stride, long long dst_ps8 /* uint4 between output planes */,
+                                long long lo8 /* > 0: the lo images are written lo8 uint4 behind dst / cen (bf16_lo) */) {
     const int c8n = ldp / 8;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_plane = (long long)Kp * c8n;
@@ -1019,7 +1029,7 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
     const long long q = i0 - (long long)pl * per_plane;
     const long long i = (long long)pl * dst_ps8 + q;
     const int row = (int)(q / c8n), c0 = (int)(q - (long long)row * c8n) * 8;
-    unsigned w[4] = {0u, 0u, 0u, 0u}, wc[4] = {0u, 0u, 0u, 0u};
+    unsigned w[4] = {0u, 0u, 0u, 0u}, wc[4] = {0u, 0u, 0u, 0u}, wl[4] = {0u, 0u, 0u, 0u}, wcl[4] = {0u, 0u, 0u, 0u};
     if (row < N && c0 < ld) {                                    // ld % 8 == 0: a chunk is all-in or all-out
         const float* s = src + (long long)pl * ps_src + (long long)row * ld + c0;
         const float4 a = reinterpret_cast<const float4*>(s)[0], b = reinterpret_cast<const float4*>(s)[1];
@@ -1028,18 +1038,22 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = c0 + j < nvalid ? v[j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = bf16_rne(v[2 * j]) | (bf16_rne(v[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) bf16_pair(v[2 * j], v[2 * j + 1], w[j], wl[j]);
         if (cen) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float* cs = colsum + (long long)pl * colsum_stride;
                 const float m0 = cs[c0 + 2 * j] * inv_rows, m1 = cs[c0 + 2 * j + 1] * inv_rows;
-                wc[j] = bf16_rne(v[2 * j] - m0) | (bf16_rne(v[2 * j + 1] - m1) << 16);
+                bf16_pair(v[2 * j] - m0, v[2 * j + 1] - m1, wc[j], wcl[j]);
             }
         }
     }
     if (dst) dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
     if (cen) cen[i] = make_uint4(wc[0], wc[1], wc[2], wc[3]);
+    if (lo8 > 0) {
+        if (dst) dst[lo8 + i] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        if (cen) cen[lo8 + i] = make_uint4(wcl[0], wcl[1], wcl[2], wcl[3]);
+    }
 }
 
 // Hoisted propagation: channel block [col0, col0 + w) of the rows (n, b) of `T` plane sets, packed as the
@@ -1055,7 +1069,7 @@ __global__ void k_plane_to_bf16(const float* __restrict__ src, long long ps_src,
 __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t, int N, long long ld, int Cp, int col0, int w, int B,
                                  int T, int Kp, int ldo, uint4* __restrict__ dst, long long src_y, long long dst_y,
                                  const float* __restrict__ mu, long long mu_t, long long mu_y, float inv_rows, int coff,
-                                 int ncw, int tmul, int toff) {
+                                 int ncw, int tmul, int toff, long long lo8 /* > 0: lo image lo8 uint4 behind dst */) {
     const int ncols = T * B * w;
     const int c8n = (ncw > 0 ? ncw : ldo) / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1063,7 +1077,7 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
     const int row = (int)(i / c8n), c0 = (int)(i - (long long)row * c8n) * 8;
     src += (long long)blockIdx.y * src_y;
     if (mu) mu += (long long)blockIdx.y * mu_y;
-    unsigned wd[4] = {0u, 0u, 0u, 0u};
+    unsigned wd[4] = {0u, 0u, 0u, 0u}, wl[4] = {0u, 0u, 0u, 0u};
     long long dcol = coff + c0;                       // destination column of the chunk
     if (tmul != 1 && c0 < ncols) {                    // (t*B + b)*w + j  ->  ((tmul*t + toff)*B + b)*w + j : chunks never straddle a step when B*w % 8 == 0
         const int t = c0 / (B * w);
@@ -1095,9 +1109,11 @@ __global__ void k_pack_cols_bf16(const float* __restrict__ src, long long src_t,
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wd[e] = bf16_rne(v[2 * e]) | (bf16_rne(v[2 * e + 1]) << 16);
+        for (int e = 0; e < 4; ++e) bf16_pair(v[2 * e], v[2 * e + 1], wd[e], wl[e]);
     }
-    dst[(long long)blockIdx.y * dst_y + ((long long)row * ldo + dcol) / 8] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    const long long o = (long long)blockIdx.y * dst_y + ((long long)row * ldo + dcol) / 8;
+    dst[o] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    if (lo8 > 0) dst[lo8 + o] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
 }
 // dst[n][b*Cp + col0 + j] += tmp[n][coff + b*w + j]   (j < wuse <= w): the go-symbol share of a propagated input gradient
 // (tmp: the sum of `nsplit` split-K partial products `slab` floats apart, added in a fixed order)
@@ -1209,7 +1225,7 @@ __global__ void k_zero_pad_rows(uint4* __restrict__ planes, long long psb8, int 
 //   transpose == 1:  dst[(r0 + i) * ldd + c0 + j] = bf16(S[j][i])        backward stack [S1^T | T2^T | S2^T | T2^T]
 // for i < N, j < Kp (zero for j >= N: the K padding of the GEMM's A operand).  32 x 32 tiles through LDS.
 __global__ void k_stack_build(const float* __restrict__ S, long long lds_, int N, int Kp, int transpose,
-                              uint16_t* __restrict__ dst, long long ldd, long long r0, long long c0) {
+                              uint16_t* __restrict__ dst, long long ldd, long long r0, long long c0, long long lo_off /* > 0: lo image */) {
     __shared__ float t[32][33];
     const int bi = blockIdx.y * 32, bj = blockIdx.x * 32;       // output tile origin (i, j)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads
@@ -1225,7 +1241,12 @@ __global__ void k_stack_build(const float* __restrict__ S, long long lds_, int N
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const int i = bi + k, j = bj + tx;
-        if (i < N && j < Kp) dst[(r0 + i) * ldd + c0 + j] = (uint16_t)bf16_rne(transpose ? t[tx][k] : t[k][tx]);
+        if (i < N && j < Kp) {
+            const float v = transpose ? t[tx][k] : t[k][tx];
+            const unsigned h = bf16_rne(v);
+            dst[(r0 + i) * ldd + c0 + j] = (uint16_t)h;
+            if (lo_off > 0) dst[lo_off + (r0 + i) * ldd + c0 + j] = (uint16_t)bf16_lo(v, h);
+        }
     }
 }
 

@@ -117,8 +117,11 @@ __global__ __launch_bounds__(256) void wp_stream_kernel(const WpP p) {
     // ceil(row blocks / 8) * 8 * column blocks.
     const int xcd = (int)(blockIdx.x & 7);
     const long long slot = blockIdx.x >> 3;
-    const int cb = (int)(slot % p.ncb);
-    const long long rbk = (slot / p.ncb) * 8 + xcd;
+    // (a division by a run-time value is VALU work: its uniform result is moved back to SGPRs HERE, far from the first LDS-DMA issue -
+    //  left in VGPRs, every slab address below would be a v_readfirstlane 3 - 4 wait states before the asm load that reads it, and a
+    //  VMEM instruction needs 5 after a VALU write of its SGPR base: tools/isa_hazards.py found exactly that in round 5)
+    const int cb = __builtin_amdgcn_readfirstlane((int)(slot % p.ncb));
+    const long long rbk = (long long)__builtin_amdgcn_readfirstlane((int)(slot / p.ncb)) * 8 + xcd;
     if (rbk * 128 >= p.R) return;                                           // (padding of the last round; uniform over the workgroup)
     const long long r0 = rbk * 128 + 32 * w;
     const long long rl = p.R - 1;

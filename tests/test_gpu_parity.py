@@ -371,6 +371,8 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192"),
     (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment"),
     (45, 6, 32, 32, 2, "cheb_k=2: streaming weight pool with 2 propagated planes (wp_stream_kernel<2|4, 2, ..>), fp32 planes"),
+    (400, 8, 32, 32, 3, "N > 352 in a bf16x3 session: the bf16-resident data flow with hi/lo operand pairs (x3r: stacked adjacency, hoisted forward and "
+                        "backward, one adjacency-gradient product per stack, three MFMAs per product) - the f32 session of the fixture runs the tiled path"),
     (33, 4, 10, 6, 2, "H % 4 != 0: scalar GRU-backward kernels (k_cell_bwd_b / ca / c), scalar slab reduction (k_wunprep), tiled d-grad and weight pool"),
     (48, 6, 32, 32, 3, "ycov_dim=5: decoder input of 6 channels (two column quads beside H_dec = 64): under MCRN_HOIST_FWD=2 the hoisted "
                        "forward product and the state-only backward chain at an input width round 4's gathered first hop did not cover"),
@@ -591,7 +593,7 @@ BASELINE_SHAPES = {
     # name: (N, T, H, M, D, reduced B, reduced T, full B)
     "metrla":  (207, 12, 64, 20, 64, 64, 12, 64),      # full batch: the benchmarked shape itself, fwd + bwd
     "pemsbay": (325, 12, 64, 20, 64, 4, 12, 64),
-    "expytky": (1843, 6, 32, 10, 32, 4, 6, 32),
+    "expytky": (1843, 6, 32, 10, 32, 8, 3, 32),     # (B = 8: the batch the hoisted backward - and with it the x3r data flow of a bf16x3 session - takes)
     "syn8192": (8192, 12, 64, 20, 64, 2, 2, 32),
 }
 

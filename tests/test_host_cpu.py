@@ -217,6 +217,28 @@ def test_shipped_kernels_use_no_packed_fp32_valu():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_shipped_kernels_do_not_spill():
+    """Build guard: no GEMM-shaped or streaming kernel of the shipped library uses scratch (register spills), and the few fused-propagation
+    variants that do stay within what was measured.  Round 5 shipped, for a few commits, a 256x256 ping-pong bf16 GEMM tile with 556 B/lane
+    of scratch after an accumulator-preload edit: every parity test passed and the bf16-mode step was simply a tenth slower
+    (profiles/r5/experiments.md section 10).  tools/scratch_report.py reads the sizes from the code objects' metadata."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "megacrn_amd", "libmegacrn_hip.so")
+    spec = importlib.util.spec_from_file_location("scratch_report", os.path.join(root, "tools", "scratch_report.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(so) and os.path.exists(mod.READELF)):
+        pytest.skip("library or LLVM binutils not present")
+    sizes = mod.scratch_sizes(so)
+    assert len(sizes) > 200 and any(k.startswith("gemm_bf16_pp_kernel<") for k in sizes)      # we really looked at the kernels
+    # known, measured spills of the widest fused two-hop variants (K = 3 planes of a 7- or 8-fragment adjacency row band) and one d-grad form
+    allowed = {"prop2_fwd_kernel<8, 3>": 160, "prop2_bwd_kernel<8, 3>": 72, "prop2_fwd_kernel<7, 3>": 64, "prop2_bwd_kernel<7, 3>": 24,
+               "dgrad_stream_kernel<8, 2>": 20}
+    bad = {k: v for k, v in sizes.items() if v > allowed.get(k, 0)}
+    assert not bad, f"kernels with new register spills (bytes per lane): {bad}"
+
+
 def test_shipped_kernels_have_no_valu_sgpr_to_vmem_hazard():
     """Build guard for the inline-asm loads (prop_small.h's streamed adjacency fragments, the LDS-DMA issue blocks): a VMEM
     instruction that reads an SGPR pair written by a VALU instruction (v_readfirstlane / v_readlane ...) needs 5 wait states,

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o bf16_gemm_test bf16_gemm_test.hip
 //   ./bf16_gemm_test probe                      # print the ds_read_b64_tr_b16 lane mapping
 //   ./bf16_gemm_test M N seglen nseg nn|nt cfg nsplit reps [with_bf16_copy]
+//   env X3=1: hi/lo operand pairs (Bf16GemmP::nterm = 3: A_hi B_hi + A_hi B_lo + A_lo B_hi) checked against the fp32 values' float64 product;
 //   env CB_ONLY=1: time the bf16-only output form; NO_OUT=1: time without any store.  Builds with -DMCRN_BF16_ABL=<bits> take one
 //   stream out of the K loop / add the in-kernel clock probe (gemm_bf16.h; profiles/r4/experiments.md section 13).
 #include <hip/hip_runtime.h>
@@ -53,23 +54,35 @@ int main(int argc, char** argv) {
     const long long lda = (long long)nseg * Kp;
     std::mt19937 rng(1234);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
-    std::vector<uint16_t> hA((size_t)M * lda, 0), hB;
+    const bool x3 = getenv("X3") != nullptr;
+    // X3: the operands are fp32 values held as bf16 hi + lo pairs; the lo images sit behind the hi ones (vectors twice as long)
+    std::vector<float> fA, fB;
+    auto putf = [&](std::vector<uint16_t>& h, std::vector<float>& f, size_t i, size_t lo_off, float v) {
+        const uint16_t hi = f2bf(v);
+        h[i] = hi;
+        if (x3) { f[i] = v; h[lo_off + i] = f2bf(v - bf2f(hi)); } 
+    };
+    const size_t nA = (size_t)M * lda;
+    std::vector<uint16_t> hA(nA * (x3 ? 2 : 1), 0), hB;
+    if (x3) fA.assign(nA, 0.f);
     for (int m = 0; m < M; ++m)
         for (int s = 0; s < nseg; ++s)
-            for (int k = 0; k < seglen; ++k) hA[(size_t)m * lda + (size_t)s * Kp + k] = f2bf(U(rng));
+            for (int k = 0; k < seglen; ++k) putf(hA, fA, (size_t)m * lda + (size_t)s * Kp + k, nA, U(rng));
     long long ldb, bseg;
     if (btr) {   // B[seg][k][n], n contiguous, k rows padded to Kp with zeros
         ldb = N; bseg = (long long)Kp * N;
-        hB.assign((size_t)nseg * Kp * N, 0);
+        hB.assign((size_t)nseg * Kp * N * (x3 ? 2 : 1), 0);
+        if (x3) fB.assign((size_t)nseg * Kp * N, 0.f);
         for (int s = 0; s < nseg; ++s)
             for (int k = 0; k < seglen; ++k)
-                for (int n = 0; n < N; ++n) hB[(size_t)s * bseg + (size_t)k * ldb + n] = f2bf(U(rng));
+                for (int n = 0; n < N; ++n) putf(hB, fB, (size_t)s * bseg + (size_t)k * ldb + n, (size_t)nseg * Kp * N, U(rng));
     } else {     // B[n][seg][k], k padded to Kp with zeros (same layout as A)
         ldb = lda; bseg = Kp;
-        hB.assign((size_t)N * ldb, 0);
+        hB.assign((size_t)N * ldb * (x3 ? 2 : 1), 0);
+        if (x3) fB.assign((size_t)N * ldb, 0.f);
         for (int n = 0; n < N; ++n)
             for (int s = 0; s < nseg; ++s)
-                for (int k = 0; k < seglen; ++k) hB[(size_t)n * ldb + (size_t)s * Kp + k] = f2bf(U(rng));
+                for (int k = 0; k < seglen; ++k) putf(hB, fB, (size_t)n * ldb + (size_t)s * Kp + k, (size_t)N * ldb, U(rng));
     }
     uint16_t *dA, *dB, *dZ; float *dC; uint16_t* dCb;
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2 + 256)); CK(hipMalloc(&dZ, 256));
@@ -83,6 +96,7 @@ int main(int argc, char** argv) {
     p.nseg = nseg; p.seg_len = seglen; p.a_seg = Kp; p.b_seg = bseg; p.M = M; p.N = N;
     p.C = dC; p.cm = rm_plain(N); p.alpha = 1.f; p.beta = 0.f; p.slab = (long long)M * N;
     p.Cb = (ns == 1 && with_cb) ? dCb : nullptr; p.cbm = rm_plain(N); p.xcd = 1;
+    if (x3) { p.nterm = 3; p.a_lo = (long long)nA; p.b_lo = (long long)(hB.size() / 2); }
     hipError_t e = launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 2; }
     CK(hipDeviceSynchronize());
@@ -101,8 +115,9 @@ int main(int argc, char** argv) {
             double s = 0;
             for (int sg = 0; sg < nseg; ++sg)
                 for (int k = 0; k < seglen; ++k) {
-                    const double a = bf2f(hA[(size_t)m * lda + (size_t)sg * Kp + k]);
-                    const double b = btr ? bf2f(hB[(size_t)sg * bseg + (size_t)k * ldb + n]) : bf2f(hB[(size_t)n * ldb + (size_t)sg * bseg + k]);
+                    const size_t ia = (size_t)m * lda + (size_t)sg * Kp + k, ib = btr ? (size_t)sg * bseg + (size_t)k * ldb + n : (size_t)n * ldb + (size_t)sg * bseg + k;
+                    const double a = x3 ? (double)fA[ia] : (double)bf2f(hA[ia]);
+                    const double b = x3 ? (double)fB[ib] : (double)bf2f(hB[ib]);
                     s += a * b;
                 }
             double got = 0;
@@ -122,7 +137,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) launch_gemm_bf16(p, btr, cfg, nsplit, 0, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    const double fl = 2.0 * M * N * (double)nseg * seglen;
+    const double fl = 2.0 * M * N * (double)nseg * seglen;        // algorithmic (X3: three MFMAs per product)
     printf("  %s  %.2f us/launch  %.1f TFLOP/s\n", ok ? "OK " : "BAD", 1e3 * ms / reps, fl / (ms / reps * 1e-3) / 1e12);
 #if MCRN_BF16_ABL & 8
     {
