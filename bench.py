@@ -372,7 +372,10 @@ def make_trainer(config_name, B, prec, device, rank, tile_cache=False, save_tile
     tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=SC_MEAN, scaler_std=SC_STD)
     batch = synth(cfg, B, 1234 + rank, device)
     tr.tiles_cached = bool(tile_cache) and import_tile_cache(config_name, B, prec)
+    t_prep = time.perf_counter()
     tr._prepare(batch[0])              # workspace + one-off GEMM tile autotune (only signatures the table lacks): never inside a timed region
+    torch.cuda.synchronize()
+    tr.autotune_s = time.perf_counter() - t_prep      # (+ dp.share_autotune's broadcast at world > 1: DESIGN.md section 6)
     if save_tiles:
         os.makedirs(os.path.dirname(os.path.abspath(save_tiles)), exist_ok=True)
         json.dump({"config": config_name, "B": B, "precision": prec, "lib_version": _lib.lib.mcrn_version(),
@@ -411,6 +414,7 @@ def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True, prec
                                    f"cheb_k=3, batch {B}, full train step"},
             "dtype": prec, "parity_tolerance": tol, "value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(ms, 4),
             "steps": steps, "warmup": warmup, "tile_table_cached": bool(getattr(tr, "tiles_cached", False)),
+            "autotune_s": round(tr.autotune_s, 2),
             **step_traffic(name, prec, ms), "roofline": roof}
 
 
@@ -474,7 +478,11 @@ def main():
     # arithmetic: bf16x3 (fp32-equivalent, the 1e-4 parity mode) for the small graphs; the large graphs default to the
     # bf16-resident propagation mode (own stated tolerance, tests/test_gpu_parity.py::test_bf16_mode_*)
     prec = args.precision or ("bf16" if cfg["N"] >= 1024 else "bf16x3")
-    tr, batch = make_trainer(args.config, B, prec, device, rank, save_tiles=args.save_tiles if rank == 0 else None)
+    # (a committed tile table of exactly this config / batch / arithmetic / library version is adopted - today only N = 8192 has one -
+    #  unless this run is the one that writes it)
+    tr, batch = make_trainer(args.config, B, prec, device, rank, tile_cache=not args.save_tiles,
+                             save_tiles=args.save_tiles if rank == 0 else None)
+    autotune_s = tr.autotune_s
     x, ycov, y = batch
     dtype = prec
 
@@ -616,6 +624,7 @@ def main():
                        "global_batch": gb, "parallelism": f"dp{world}"},
             "step_alg_tflops": round(step_flops * world / (dt / args.steps) / 1e12, 2),
             "kernel_launches_per_step": launches, "final_loss": round(final_loss, 5),
+            "autotune_s": round(autotune_s, 2),      # workspace + one-off tile autotune (+ tile-table broadcast), before the timed region
             "teacher_regime": f"timed steps start at batches_seen = {args.batches_seen}: teacher-forcing probability "
                               f"{2000.0 / (2000.0 + float(np.exp(min(args.batches_seen, 10 ** 6) / 2000.0))):.3f} "
                               f"(cl_decay_steps 2000, model/MegaCRN.py:146-147); value_no_teacher = no step teacher-forced",

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
 }
 
 // ---- host launcher ------------------------------------------------------------------------
-#ifndef MCRN_PROBE   // compile-only probes (tools/scratch/probe_prop.hip) skip the launchers: they instantiate every tile configuration
+#ifndef MCRN_PROBE   // compile-only probes (tools/probe_prop.hip) skip the launchers: they instantiate every tile configuration
 template <int BM, int BN, int WGM, int WGN, bool AKC, bool BKC, int ROLE>
 static inline hipError_t launch_one_x3(const GemmP& p, hipStream_t st) {
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.nsplit);

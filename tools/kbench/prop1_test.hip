@@ -16,6 +16,39 @@
 using namespace mcrn;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+#ifdef MCRN_TIMELINE
+// -DMCRN_TIMELINE=1|2 build (`hipcc ... -DMCRN_TIMELINE=2 -o prop1_test_tl`): thread 0 of every workgroup stamps the 100 MHz clock at the
+// kernel's phase boundaries (prop_small.h MCRN_TL); =2 drains the memory counters first, so a phase includes the latency of what it issued.
+// One launch on a plane set the previous launches did not touch last; prints, per phase, the mean / max over the workgroups.
+template <class F>
+static hipError_t tl_dump(int kind, int nstamp, F launch) {
+    static unsigned long long h[10][512][12];
+    hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return e;
+    memset(h, 0, sizeof h);
+    e = hipMemcpyToSymbol(HIP_SYMBOL(mcrn::g_tl), h, sizeof h); if (e != hipSuccess) return e;
+    e = launch(); if (e != hipSuccess) return e;
+    e = hipDeviceSynchronize(); if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(h, HIP_SYMBOL(mcrn::g_tl), sizeof h); if (e != hipSuccess) return e;
+    unsigned long long t0 = ~0ull, t1 = 0; int nwg = 0;
+    for (int b = 0; b < 512; ++b) {
+        if (!h[kind][b][0]) continue;
+        ++nwg;
+        for (int i = 0; i < nstamp; ++i) if (h[kind][b][i]) { t0 = t0 < h[kind][b][i] ? t0 : h[kind][b][i]; t1 = t1 > h[kind][b][i] ? t1 : h[kind][b][i]; }
+    }
+    printf("    timeline kind %d: %d workgroups stamped, first stamp -> last stamp %.2f us\n", kind, nwg, (t1 - t0) / 100.0);
+    for (int i = 0; i + 1 < nstamp; ++i) {
+        double sum = 0, mx = 0, st = 0; int n = 0;
+        for (int b = 0; b < 512; ++b) {
+            if (!h[kind][b][i] || !h[kind][b][i + 1] || h[kind][b][i + 1] < h[kind][b][i]) continue;
+            const double d = (h[kind][b][i + 1] - h[kind][b][i]) / 100.0;
+            sum += d; mx = d > mx ? d : mx; st += (h[kind][b][i] - t0) / 100.0; ++n;
+        }
+        if (n) printf("      phase %d -> %d: mean %.2f us  max %.2f us   (mean start +%.2f us, %d wgs)\n", i, i + 1, sum / n, mx, st / n, n);
+    }
+    return hipSuccess;
+}
+#endif
+
 int main(int argc, char** argv) {
     if (argc < 3) { printf("usage: prop1_test N ncols [reps]\n"); return 1; }
     const int N = atoi(argv[1]), ncols = atoi(argv[2]), reps = argc > 3 ? atoi(argv[3]) : 40;
@@ -157,6 +190,9 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  prop2_fwd (2 serial hops)           err %.2e   %.1f us\n", ef, 1e3 * ms / reps);
+#ifdef MCRN_TIMELINE
+        CK(tl_dump(0, 10, [&]() { q.base = dZ + (size_t)3 * ZT; return launch_prop2_fwd(q, 0); }));
+#endif
         if (N <= 352 && ncols % 132 == 0) {          // state columns only (decoder geometry: H = 128 of Cp = 132)
             Prop2P q2 = q; q2.cps = 2; q2.cstride = 132; q2.nunits = (ncols / 132) * 2;
             CK(hipEventRecord(e0, 0));
@@ -177,6 +213,9 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  prop2_bwd (2 serial hops)           err %.2e   %.1f us\n", eb, 1e3 * ms / reps);
+#ifdef MCRN_TIMELINE
+        CK(tl_dump(1, 10, [&]() { q.base = dZ + (size_t)3 * ZT; return launch_prop2_bwd(q, 0); }));
+#endif
     }
     if (N <= PROP2_MAX_N) {   // the same chain without the d1t write-back (Prop2P::no_d1: the model path's form since round 5)
         CK(reset());

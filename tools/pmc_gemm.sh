@@ -7,7 +7,7 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIV
 P3="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE TA_TA_BUSY_sum"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i -o r -- python3 $GRAFT_REPO_ROOT/tools/scratch/one_gemm.py "$@" 8 > /dev/null 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i -o r -- python3 $GRAFT_REPO_ROOT/tools/one_gemm.py "$@" 8 > /dev/null 2>&1
   i=$((i+1))
 done
 python3 - "$tag" <<'PY'

@@ -24,6 +24,6 @@ python bench.py --config expytky --no-secondary --no-cpu-baseline --no-roofline 
 MEGACRN_LIB=$GRAFT_REPO_ROOT/megacrn_amd/libmegacrn_hip_slp.so python bench.py --config expytky --no-secondary --no-cpu-baseline --no-roofline 2>/dev/null | q "expytky slp"
 echo "== parity with the SLP library (subset) + race script"
 MEGACRN_LIB=$GRAFT_REPO_ROOT/megacrn_amd/libmegacrn_hip_slp.so timeout 900 python -m pytest tests -m gpu -x -q -k "(model_train_step or golden or kernel_variants or trajectory or full_size_metrla or half_batches or bf16_mode_train or large_graph or baseline_config) and not alternative_paths" 2>&1 | tail -4
-MEGACRN_LIB=$GRAFT_REPO_ROOT/megacrn_amd/libmegacrn_hip_slp.so timeout 300 python tools/scratch/dbg_race.py 6 2>&1 | tail -8
+# (the race replay script of rounds 2-4, tools/scratch/dbg_race.py, ran here; removed with tools/scratch at the end of round 5)
 } > $out/r5a.log 2>&1
 tail -50 $out/r5a.log
