@@ -230,10 +230,10 @@ struct Side {
     hipStream_t st2 = nullptr;                   // second helper queue: the decoder's deferred weight gradients (round 4), so that the
     hipEvent_t fork2, join2;                     // encoder's adjacency-gradient launches are not queued behind ~0.5 ms of them
     bool any2 = false;
-    static const int NSLOT = 6;                  // plane sets: (update, gate) x NPAIR cells of the BPTT loop in flight
+    static const int NSLOT = 48;                 // plane sets: (update, gate) x the cells of the BPTT loops in flight (ModelPlan::MAXPAIR pairs)
     hipEvent_t ready[NSLOT], done[NSLOT], join, fork, mid;
-    bool ok = false, pending[NSLOT] = {false, false, false, false, false, false}, any = false;
-    bool paired[NSLOT] = {false, false, false, false, false, false};   // done[buf] and done[buf ^ 1] mark the SAME launch (merged per cell)
+    bool ok = false, pending[NSLOT] = {}, any = false;
+    bool paired[NSLOT] = {};                     // done[buf] and done[buf ^ 1] mark the SAME launch (merged per cell)
 };
 static Side g_side;
 static bool g_use_side = true;
@@ -939,6 +939,12 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
     }
     const bool small = use_prop_small(u, s) && aligned16(dP);
     const bool fused_bwd = use_prop2(u, s) && aligned16(dP) && dT != nullptr;
+    // The adjacency-gradient launch of this cell goes to the helper stream behind the fused chain below.  Its `ready` event is ATTACHED to
+    // that chain's dispatch (completion signal of the kernel itself) instead of recorded behind it: a recorded event is a marker packet
+    // in the caller's queue, and the next kernel there starts ~7.5 us later; behind the attached signal it is ~5 us (round 5: one such
+    // bubble per cell; with the per-cell plane sets of ModelPlan::flat METR-LA +1.2 %, PEMS-BAY +0.8 %: profiles/r5/experiments.md 12).
+    const bool ds_fused_path = (small || (s.N > 256 && s.N <= PROP2_MAX_N && fused_bwd && (s.ld % 4) == 0)) && aligned16(X);
+    const bool ready_attached = side && fused_bwd && ds_fused_path && (!cell_ds || cell_ds_last);
     if (fused_bwd) {
         // whole S^T chain for both supports in one launch: d1t_s = d1_s + S_s^T e2_s (written back),
         // dP[0] += S_1^T d1t_1 + S_2^T d1t_2.  The adjacency-gradient GEMM below then reads d1t / e2.
@@ -954,6 +960,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             q.cps = s.H / 64; q.nunits = s.B * q.cps; q.cstride = s.Cp;
             ex = alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
         }
+        if (ready_attached) q.ev1 = g_side.ready[buf];
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, alg);
     } else if (s.K == 3 && small) {
         PropP q;
@@ -1018,7 +1025,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             const double ex = nblk * q.nseg * 2.0 * (double)s.N * s.N * (double)s.ld;
             hipStream_t ds_st = st;
             if (side) {
-                CK(hipEventRecord(g_side.ready[buf], st));
+                if (!ready_attached) CK(hipEventRecord(g_side.ready[buf], st));
                 CK(hipStreamWaitEvent(g_side.st, g_side.ready[buf], 0));
                 ds_st = g_side.st;
             }
@@ -1501,8 +1508,12 @@ struct ModelPlan {
     float *dP, *dQ, *dTu, *dTg;
     // NPAIR plane-set pairs (pair 0 = dP, dQ): the cells of a BPTT loop rotate through them, so the helper stream's
     // adjacency-gradient launch may lag NPAIR - 1 cells behind the main stream before the main stream has to wait
-    static const int NPAIR = 3;
-    float *dPp[NPAIR], *dQp[NPAIR];
+    static const int NPAIR = 3, MAXPAIR = 24;
+    // flat (round 5, small graphs): EVERY cell of both BPTT loops has its own pair (decoder cell t: pair t, encoder cell t: pair T_out + t),
+    // so the caller's stream never waits for the helper stream's adjacency gradient before it writes a plane set - a wait on an event
+    // that fired long ago still costs a barrier packet in the caller's queue (~6 us per cell).  288 GB of HBM: 1.7 GB at METR-LA.
+    int npair; bool flat;
+    float *dPp[MAXPAIR], *dQp[MAXPAIR];
     float *dU_e, *dG_e, *dU_d, *dG_d;
     float *dacc_e, *dacc_d, *dhn_d, *dxin_e, *dxin_d, *dgo;
     float *dval, *dsc, *dq;
@@ -1593,7 +1604,13 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.dP = b.take<float>(zmax);
     P.dQ = b.take<float>(zmax);
     P.dPp[0] = P.dP; P.dQp[0] = P.dQ;
-    for (int i = 1; i < ModelPlan::NPAIR; ++i) { P.dPp[i] = b.take<float>(zmax); P.dQp[i] = b.take<float>(zmax); }
+    {
+        const int want = d->T_in + d->T_out;
+        P.flat = !P.bf16 && d->precision == MCRN_BF16X3 && want <= ModelPlan::MAXPAIR &&
+                 (double)want * 2.0 * (double)zmax * sizeof(float) <= 8e9;
+        P.npair = P.flat ? want : ModelPlan::NPAIR;
+    }
+    for (int i = 1; i < P.npair; ++i) { P.dPp[i] = b.take<float>(zmax); P.dQp[i] = b.take<float>(zmax); }
     {
         size_t pmax = (size_t)(P.se.PS > P.sd.PS ? P.se.PS : P.sd.PS);
         P.dTu = b.take<float>(pmax * PROPT_MAX_X);        // extra partial planes of plane 0 (K splits 1 .. 3 / second support)
@@ -2083,7 +2100,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         for (int t = To - 1; t >= 0; --t) {
             const bool last = t == To - 1;
             const int use_next = (!last && !(teacher && teacher[t])) ? 1 : 0;
-            const int pair = t % ModelPlan::NPAIR;
+            const int pair = P.flat ? t : t % ModelPlan::NPAIR;
             // hoisted backward (small graphs): nothing reads the propagated gradient of this cell's input channels when its go symbol
             // was known before the stack started - zero (t = 0) or the label of a teacher-forced step (no use_next at t - 1)
             Shp sdt = sd;
@@ -2152,6 +2169,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     // there the narrower the better until they stop fitting the encoder BPTT: 24 workgroups (budget 32) -> METR-LA 11 026 / 10 995
     // vs 10 781 (one helper queue, 120 workgroups) and 10 633 before; PEMS-BAY 6 314 / 6 276 vs 6 184; 12 workgroups: 9 410.
     const bool own_queue = g_side.ok && ws_ == g_side.st2;
+    // (bf16 mode re-measured in round 5 - 256 / 192 / 128 / 96 / 72 workgroups: 4 705 / 4 711 / 4 751 / 4 714 / 4 699 samples/s at EXPY-TKY,
+    //  means of three runs inside their spread; 48: -3 %, 24: -17 %: the tail waits for them.  Full width kept.)
     const int dec_budget = ws_ != st ? (P.bf16 ? NSLAB_W : (own_queue ? 32 : NSLAB_W / 2)) : NSLAB_W;
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     int ns2 = 0;
@@ -2204,7 +2223,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
         int xu = 0, xg = 0;
         for (int t = Ti - 1; t >= 0; --t) {
             const bool first = t == Ti - 1;
-            const int pair = t % ModelPlan::NPAIR, prev = (t + 1) % ModelPlan::NPAIR;   // (the cell processed just before: t + 1)
+            const int pair = P.flat ? To + t : t % ModelPlan::NPAIR;
+            const int prev = P.flat ? To + t + 1 : (t + 1) % ModelPlan::NPAIR;           // (the cell processed just before: t + 1)
             float* dPt = P.dPp[pair];
             float* dQt = P.dQp[pair];
             if (!first)   // C(t+1) + A(t) in one launch (dh' of step t IS the accumulated state gradient)

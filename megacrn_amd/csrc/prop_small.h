@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
             if (e_ != hipSuccess) return e_;                                                              \
             set_ = true;                                                                                  \
         }                                                                                                 \
-        if ((P).ev0 && (P).ev1)                                                                           \
+        if ((P).ev1)   /* (ev1 alone: a completion event for another stream's wait, attached to the dispatch instead of a marker packet) */ \
             hipExtLaunchKernelGGL((KERN<NF_, CT_>), GRID, dim3(64 * NF_), lds_, st, (hipEvent_t)(P).ev0, (hipEvent_t)(P).ev1, 0, P); \
         else                                                                                              \
         hipLaunchKernelGGL((KERN<NF_, CT_>), GRID, dim3(64 * NF_), lds_, st, P);                          \

@@ -374,6 +374,8 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     (400, 8, 32, 32, 3, "N > 352 in a bf16x3 session: the bf16-resident data flow with hi/lo operand pairs (x3r: stacked adjacency, hoisted forward and "
                         "backward, one adjacency-gradient product per stack, three MFMAs per product) - the f32 session of the fixture runs the tiled path"),
     (33, 4, 10, 6, 2, "H % 4 != 0: scalar GRU-backward kernels (k_cell_bwd_b / ca / c), scalar slab reduction (k_wunprep), tiled d-grad and weight pool"),
+    (36, 3, 16, 8, 13, "T_in + T_out = 26 > 24: more BPTT cells than plane-set pairs - the rotating three-pair form with the caller's guard waits "
+                       "(up to 24 cells every cell owns its pair, ModelPlan::flat)"),
     (48, 6, 32, 32, 3, "ycov_dim=5: decoder input of 6 channels (two column quads beside H_dec = 64): under MCRN_HOIST_FWD=2 the hoisted "
                        "forward product and the state-only backward chain at an input width round 4's gathered first hop did not cover"),
 ])
@@ -390,7 +392,7 @@ def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
     x = rng.standard_normal((B, T, N, 1)).astype(np.float32)
     ycov = rng.random((B, T, N, yd)).astype(np.float32)
     y = rng.standard_normal((B, T, N, 1)).astype(np.float32)
-    teacher = [False, True, True][:T]
+    teacher = ([False, True, True] * 5)[:T]
     m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000, ycov_dim=yd)
     model = build(amd, P, m).train()
     model._teacher_flags = lambda labels, bs: teacher
