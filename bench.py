@@ -403,7 +403,7 @@ def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True, prec
         tr.train_step(*batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    regimes = regime_legs(tr, batch, B, min(steps, 6), 1, torch.cuda.synchronize) if regimes else {}
+    regimes = regime_legs(tr, batch, B, steps, 2, torch.cuda.synchronize) if regimes else {}
     roof = roofline_of(tr, batch, cfg, name, B, prec, nrep=nrep)
     ms = 1e3 * dt / steps
     tol = {"bf16": "1e-2 (bf16-resident propagation operands; measured <= 5.4e-3)", "bf16x3": "1e-4 (the tolerance north_star states)",
