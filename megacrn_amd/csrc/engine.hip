@@ -988,7 +988,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
         CKI(gemm(p, true, false, 0, ROLE_PROPT, st));
     }
     // 256 < N <= 352 (PEMS-BAY): the output-stationary kernel with column groups (ds_wide_kernel) behind the fused two-hop
-    // chain, merged per cell like the N <= 256 one, instead of one tiled split-K GEMM per call (MCRN_DS_WIDE=0)
+    // chain, merged per cell like the N <= 256 one, instead of one tiled split-K GEMM per call
     const bool wide_ds = s.N > 256 && s.N <= PROP2_MAX_N && fused_bwd && (s.ld % 4) == 0;
     const bool ds_small_path = (small || wide_ds) && aligned16(X);
     if (cell_ds && cell_ds->nseg > 0 && !ds_small_path)
@@ -1122,7 +1122,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
     // kernel runs (*ones = true), and computes them itself otherwise
     if (ones) *ones = false;
     const bool streams = wgrad_streams(s, O, Xall, dYall, step_stride, T);
-    if (Xb && !streams) FAIL("weight gradient: bf16-resident planes need the streaming kernel (shape / alignment / MCRN_WGRAD_STREAM)");
+    if (Xb && !streams) FAIL("weight gradient: bf16-resident planes need the streaming kernel (shape / alignment)");
     if (streams) {
         WgradP q;
         memset(&q, 0, sizeof q);
@@ -1266,7 +1266,7 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
     DsP cell_ds;
     cell_ds.nseg = 0;
     // The two AGCN calls of a cell share one adjacency-gradient launch (slab read and written once per cell;
-    // MCRN_DS_MERGE=0: one launch per call).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the
+    // a launch per call was the earlier form).  With a single plane-set pair this was slower (8.82 vs 7.58 ms at METR-LA: the
     // merged launch holds both sets and the main queue waited for it); cells now alternate between two pairs
     // (7.29 vs 7.39 ms).
     DsP* cds = &cell_ds;
@@ -2160,7 +2160,7 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     const bool lite = P.bf16 && P.Pb_e != nullptr;
     const long long PbS_e = (long long)P.nb * N * se.ldh, PbS_d = (long long)P.nb * N * sd.ldh;
     // Workgroups of the decoder's weight-gradient launches when they run beside the encoder BPTT on the helper stream
-    // (MCRN_WGRAD_DEC_WGS).  At full width (252 workgroups at T = 12) the two launches take every CU for ~0.35 ms and the first
+    // (`dec_budget` below).  At full width (252 workgroups at T = 12) the two launches take every CU for ~0.35 ms and the first
     // encoder cells of the main queue run at half speed; at 120 they take twice as long on half the chip and the main queue
     // keeps the other half: METR-LA 10 950 vs 10 700 / 10 630 and 10 780 / 10 805 vs 10 633 / 10 625 samples/s, PEMS-BAY 6 425 vs
     // 6 314 / 6 299 (two calls; 72 workgroups: slower again - profiles/r4/experiments.md).  The bf16 mode measured no difference
@@ -2175,9 +2175,8 @@ static int model_backward(const mcrn_dims_t* d, const mcrn_params_t* p, const in
     CKI(agcn_wgrad(sd, P.Zdec, sd.ZT, To, P.dG_d, 2 * Hd, P.dWs[2], ws_, &ns1, &on1, lite ? P.Pb_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
     int ns2 = 0;
     CKI(agcn_wgrad(sd, P.Ydec, sd.ZT, To, P.dU_d, Hd, P.dWs[3], ws_, &ns2, &on2, lite ? P.Pb_d + PbS_d : nullptr, 2 * PbS_d, (long long)N * sd.ldh, P.Xp_d, dec_budget));
-    // hoisted backward, adjacency gradient of one cell stack (K-concatenated over every AGCN call); with MCRN_BF16_DS_SIDE=1 the
-    // decoder's runs on the helper stream behind its weight gradients and overlaps the encoder BPTT; the encoder's accumulates
-    // into the same dA after the join
+    // hoisted backward, adjacency gradient of one cell stack (K-concatenated over every AGCN call): both stacks' products run on the
+    // caller's stream in the tail, the encoder's accumulating into the same dA
     auto stack_ds = [&](int e_, hipStream_t st) -> int {
         const Shp& s_ = e_ ? se : sd;
         const int T_ = e_ ? Ti : To;
