@@ -386,6 +386,14 @@ def make_trainer(config_name, B, prec, device, rank, tile_cache=False, save_tile
 LEG_INDEX = {"expytky": 3, "syn8192": 4}
 
 
+def leg_workspace_bytes(name, prec):
+    """what mcrn_model_workspace_bytes asks for the leg's shape (the library sizes for 288 GB parts: every step's planes are kept)"""
+    from megacrn_amd import _lib
+    cfg = CONFIGS[name]
+    d = _lib.Dims(cfg["B"], cfg["N"], cfg["T"], cfg["T"], 1, 1, 1, cfg["H"], cfg["M"], cfg["D"], 3, _lib.PRECISIONS[prec])
+    return int(_lib.lib.mcrn_model_workspace_bytes(C.byref(d)))
+
+
 def secondary_leg(device, steps=10, warmup=3, name="expytky", regimes=True, prec="bf16", nrep=4, tile_cache=False):
     """The north_star figure, driver-timed: forward N x N propagation at N = 1843 (EXPY-TKY shape, B = 32, T = 6, H = 32) as a
     short extra run after the headline measurement (a few seconds), in the arithmetic `prec`:
@@ -438,7 +446,7 @@ def main():
     ap.add_argument("--with-syn", action="store_true",
                     help="force the third leg (3 train steps + forward-propagation roofline of the N = 8192 stress shape, BASELINE "
                          "configs[4]; ~35 GB of workspace): by default it runs with 2 steps when profiles/tiles/ holds the tile table of "
-                         "the shape (otherwise its one-off tuning takes about a minute) and 40 GB of HBM are free")
+                         "the shape (otherwise its one-off tuning takes about a minute) and its ~85 GB fit the free HBM")
     ap.add_argument("--no-syn", action="store_true", help="skip the N = 8192 leg of the default run")
     ap.add_argument("--save-tiles", default=None, help="write the GEMM tile table of this run's shape to PATH after tuning "
                                                        "(commit it as profiles/tiles/<config>_B<batch>_<precision>.json)")
@@ -563,14 +571,15 @@ def main():
         torch.cuda.empty_cache()
 
     tertiary = None
-    # N = 8192 (BASELINE configs[4]): default when the tile table of the shape is committed (no minute of tuning) and 40 GB are free
+    # N = 8192 (BASELINE configs[4]): default when the tile table of the shape is committed (no minute of tuning) and the leg's workspace (~80 GB) fits the free HBM
     syn_auto = (args.config == "metrla" and not args.no_secondary and not args.no_roofline and not args.no_syn
                 and os.path.exists(tile_cache_path("syn8192", CONFIGS["syn8192"]["B"], "bf16")))
     if rank == 0 and world == 1 and (args.with_syn or syn_auto):
         torch.cuda.empty_cache()
         free_b = torch.cuda.mem_get_info()[0]
-        if free_b < 40e9 and not args.with_syn:
-            tertiary = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the N = 8192 workspace needs ~35 GB"}
+        need_b = leg_workspace_bytes("syn8192", "bf16") * 1.05 + 4e9        # workspace + batch, outputs, gradient views, allocator slack
+        if free_b < need_b and not args.with_syn:
+            tertiary = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the N = 8192 leg needs ~{need_b / 1e9:.0f} GB"}
         else:
             try:
                 tertiary = secondary_leg(device, steps=2 if not args.with_syn else 3, warmup=1, name="syn8192", regimes=False, nrep=1,
