@@ -64,17 +64,42 @@ def alg_flops_forward(cfg, B):
     return float(f)
 
 
-def traffic_profile(config_name, dtype):
-    """The committed PMC traffic table of this config and arithmetic (tools/pmc_traffic.sh, round 5 format): per kernel the
+PROFILES_DIR = os.path.join(ROOT, "profiles")
+
+
+def lib_identity():
+    """what a measured artefact must name to be believed: the build id of the library this process loaded"""
+    from megacrn_amd import _lib
+    return _lib.build_id()
+
+
+def traffic_profile(config_name, dtype, profiles_dir=None, build_id=None):
+    """(table, source) - the committed PMC traffic table of this config and arithmetic (tools/pmc_traffic.sh): per kernel the
     FETCH_SIZE x 2 + WRITE_SIZE bytes per launch averaged over the dispatches of ONE steady-state train step (the window
     between the last two k_clip_adam dispatches of the run: no autotuner candidates, no warm-up), and `_step` = their sum.
-    None when no such profile is committed."""
+    The table of the NEWEST profiles/r<NN>/ that holds one is taken, and only if it was measured on THIS build of the library
+    (`_meta.build_id` == mcrn_build_id()): bytes of another build divided by this run's time would be a number about nothing.
+    table is None when no table exists or the newest one is stale; source says which ({"file", "status", ...})."""
+    profiles_dir = profiles_dir or PROFILES_DIR
+    build_id = build_id if build_id is not None else lib_identity()
     suffix = "" if dtype == DEFAULT_PREC[config_name] else f"_{dtype}"
-    path = os.path.join(ROOT, "profiles", "r5", f"traffic_{config_name}{suffix}.json")
-    if not os.path.exists(path):
-        return None
+    rounds = []
+    for d in os.listdir(profiles_dir) if os.path.isdir(profiles_dir) else []:
+        if d[:1] == "r" and d[1:].isdigit() and os.path.exists(os.path.join(profiles_dir, d, f"traffic_{config_name}{suffix}.json")):
+            rounds.append((int(d[1:]), d))
+    if not rounds:
+        return None, {"status": "absent"}
+    rd = max(rounds)[1]
+    path = os.path.join(profiles_dir, rd, f"traffic_{config_name}{suffix}.json")
     d = json.load(open(path))
-    return d if "_step" in d else None
+    meta = d.get("_meta", {})
+    src = {"file": os.path.relpath(path, os.path.dirname(profiles_dir)), "measured_on_build": meta.get("build_id"),
+           "this_build": build_id, "git": meta.get("git")}
+    if "_step" not in d or meta.get("build_id") != build_id:
+        src["status"] = "stale: measured on another build of the library, not reported"
+        return None, src
+    src["status"] = "current"
+    return d, src
 
 
 def x3r_session(cfg, B, dtype):
@@ -87,7 +112,7 @@ def x3r_session(cfg, B, dtype):
 def pmc_traffic(config_name, dtype, N, x3r=False):
     """Fabric-side bytes per launch of the dominant kernel (the forward propagation) in a steady-state step:
     FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md."""
-    d = traffic_profile(config_name, dtype)
+    d, _ = traffic_profile(config_name, dtype)
     if d is None:
         return None
     # (tools/pmc_traffic.sh folds the tile parameters of the tuned GEMMs away: family<*, operand forms, ROLE>)
@@ -99,7 +124,7 @@ def pmc_traffic(config_name, dtype, N, x3r=False):
         keys = ("<*, true, false, 1>",)           # tiled gemm_*_kernel<..., AKC, !BKC, ROLE = 1>
     tot = n = 0
     for k, v in d.items():
-        if k != "_step" and any(key in k for key in keys):
+        if k[:1] != "_" and any(key in k for key in keys):
             tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
@@ -108,13 +133,14 @@ def pmc_traffic(config_name, dtype, N, x3r=False):
 def step_traffic(config_name, dtype, ms_per_step):
     """Bytes one steady-state train step moves through the L2s' fabric ports (the sum of the committed PMC table over the step's
     launches; Infinity-Cache hits are counted, MI355X_MICROARCH.md) and the rate that is at this run's step time."""
-    d = traffic_profile(config_name, dtype)
+    d, src = traffic_profile(config_name, dtype)
     if d is None:
-        return {}
+        return {"traffic_source": src}
     gb = d["_step"]["fabric_bytes"] / 1e9
-    return {"step_fabric_gb": round(gb, 3), "step_fabric_tbs": round(gb / ms_per_step, 3),
+    return {"step_fabric_gb": round(gb, 3), "step_fabric_tbs": round(gb / ms_per_step, 3), "traffic_source": src,
             "step_fabric_note": f"sum over the {d['_step']['dispatches']} dispatches of one steady-state step of (2 x FETCH_SIZE + WRITE_SIZE), "
-                                f"collected by tools/pmc_traffic.sh in its own rocprofv3 --pmc runs (profiles/r5/); / this run's ms_per_step"}
+                                f"collected by tools/pmc_traffic.sh in its own rocprofv3 --pmc runs on this build of the library "
+                                f"({src['file']}); / this run's ms_per_step"}
 
 
 def small_hoist_fwd(cfg, B):
@@ -323,6 +349,7 @@ def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 5),
             "traffic": pmc_traffic(config_name, dtype, cfg["N"], x3r_session(cfg, B, dtype)),
+            "traffic_source": traffic_profile(config_name, dtype)[1],
             "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
             "frac_of_mfma_peak": round(frac_mfma, 5), "frac_of_hbm_peak": round(frac_hbm, 5),
             "achieved_tflops": round(alg_flops / launch_s / 1e12, 3), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 1),
@@ -342,6 +369,16 @@ def tile_cache_path(config_name, B, prec):
     return os.path.join(TILE_DIR, f"{config_name}_B{B}_{prec}.json")
 
 
+def tile_cache_current(config_name, B, prec):
+    """a committed tile table of this shape exists AND was written by this build of the library"""
+    from megacrn_amd import _lib
+    path = tile_cache_path(config_name, B, prec)
+    try:
+        return os.path.exists(path) and json.load(open(path)).get("build_id") == _lib.build_id()
+    except (OSError, ValueError):
+        return False
+
+
 def import_tile_cache(config_name, B, prec):
     """GEMM tile table of this (config, batch, arithmetic) from an earlier mcrn_model_autotune on an MI355X (committed under
     profiles/tiles/ by `--save-tiles`): with it the one-off tuning of the N = 8192 shape (about a minute) costs nothing, so the SYN
@@ -352,7 +389,7 @@ def import_tile_cache(config_name, B, prec):
     if not os.path.exists(path):
         return False
     rec = json.load(open(path))
-    if rec.get("lib_version") != _lib.lib.mcrn_version():
+    if rec.get("build_id") != _lib.build_id():        # (tile slots and their kernels belong to a build: a hand-bumped version number went stale in round 5)
         return False
     try:
         _lib.autotune_import(rec["words"])
@@ -378,7 +415,7 @@ def make_trainer(config_name, B, prec, device, rank, tile_cache=False, save_tile
     tr.autotune_s = time.perf_counter() - t_prep      # (+ dp.share_autotune's broadcast at world > 1: DESIGN.md section 6)
     if save_tiles:
         os.makedirs(os.path.dirname(os.path.abspath(save_tiles)), exist_ok=True)
-        json.dump({"config": config_name, "B": B, "precision": prec, "lib_version": _lib.lib.mcrn_version(),
+        json.dump({"config": config_name, "B": B, "precision": prec, "lib_version": _lib.lib.mcrn_version(), "build_id": _lib.build_id(),
                    "words": [int(w) for w in _lib.autotune_export()]}, open(save_tiles, "w"))
     return tr, batch
 
@@ -573,13 +610,15 @@ def main():
     tertiary = None
     # N = 8192 (BASELINE configs[4]): default when the tile table of the shape is committed (no minute of tuning) and the leg's workspace (~80 GB) fits the free HBM
     syn_auto = (args.config == "metrla" and not args.no_secondary and not args.no_roofline and not args.no_syn
-                and os.path.exists(tile_cache_path("syn8192", CONFIGS["syn8192"]["B"], "bf16")))
+                and tile_cache_current("syn8192", CONFIGS["syn8192"]["B"], "bf16"))
     if rank == 0 and world == 1 and (args.with_syn or syn_auto):
         torch.cuda.empty_cache()
-        free_b = torch.cuda.mem_get_info()[0]
+        free_b, total_b = torch.cuda.mem_get_info()
         need_b = leg_workspace_bytes("syn8192", "bf16") * 1.05 + 4e9        # workspace + batch, outputs, gradient views, allocator slack
-        if free_b < need_b and not args.with_syn:
-            tertiary = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the N = 8192 leg needs ~{need_b / 1e9:.0f} GB"}
+        # (unasked, the leg takes at most HALF of the part's HBM and only memory that is free now: a default run must not crowd a co-tenant out)
+        if (free_b < need_b or need_b > 0.5 * total_b) and not args.with_syn:
+            tertiary = {"skipped": f"{free_b / 1e9:.0f} of {total_b / 1e9:.0f} GB of HBM free, the N = 8192 leg needs ~{need_b / 1e9:.0f} GB "
+                                   f"(run by default only when that is free and at most half of the part; --with-syn forces it)"}
         else:
             try:
                 tertiary = secondary_leg(device, steps=2 if not args.with_syn else 3, warmup=1, name="syn8192", regimes=False, nrep=1,

@@ -37,6 +37,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header are its whole dynamic interface. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MCRN_EINVAL (-1)
 
@@ -86,6 +90,13 @@ typedef struct mcrn_grads {
 
 const char* mcrn_last_error(void);
 int mcrn_version(void);
+/* 16 hex digits: sha256 over every source file the library was built from (csrc/Makefile).  Measured artefacts - PMC traffic tables,
+ * GEMM tile tables - record it; a consumer ignores an artefact that was measured on another build. */
+const char* mcrn_build_id(void);
+/* Debug / test: which kernel FAMILY each planned launch site of the library chose since the last reset, as "family=count\n" lines
+ * (NUL-terminated).  Returns the bytes needed incl. the NUL; writes nothing when cap is smaller.  reset != 0 clears the counters.
+ * The plan picks kernels by shape; the GPU suite uses this to assert that a case runs the kernel it was written for. */
+long long mcrn_launch_histogram(char* buf, long long cap, int reset);
 
 /* arithmetic used by the stand-alone op entry points (the model entry points take it from
  * mcrn_dims_t.precision).  Returns 0 or MCRN_EINVAL. */
@@ -230,6 +241,9 @@ int mcrn_set_gemm_cfg(int cfg);
 int mcrn_set_debug(int bits);
 int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEGACRN_LIB") or os.path.join(_HERE, "libmegacrn_hip.so")
 
 EXPORTS = [
-    "mcrn_last_error", "mcrn_version", "mcrn_last_launch_count",
+    "mcrn_last_error", "mcrn_version", "mcrn_build_id", "mcrn_last_launch_count", "mcrn_launch_histogram",
     "mcrn_model_workspace_bytes", "mcrn_model_forward", "mcrn_model_backward",
     "mcrn_supports_workspace_bytes", "mcrn_supports_forward", "mcrn_supports_backward",
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
@@ -64,6 +64,9 @@ def _load():
     vp, i, f, sz, ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
     lib.mcrn_last_error.restype = C.c_char_p
     lib.mcrn_version.restype = i
+    lib.mcrn_build_id.restype = C.c_char_p
+    lib.mcrn_launch_histogram.restype = C.c_longlong
+    lib.mcrn_launch_histogram.argtypes = [C.c_char_p, C.c_longlong, C.c_int]
     lib.mcrn_last_launch_count.restype = i
     lib.mcrn_model_workspace_bytes.restype = sz
     lib.mcrn_model_workspace_bytes.argtypes = [C.POINTER(Dims)]
@@ -136,6 +139,19 @@ lib = _load()
 
 F32, BF16X3, BF16 = 0, 1, 2
 PRECISIONS = {"f32": F32, "bf16x3": BF16X3, "bf16": BF16}
+
+
+def build_id() -> str:
+    """16 hex digits identifying the sources this library was built from (csrc/Makefile); measured artefacts carry it."""
+    return lib.mcrn_build_id().decode()
+
+
+def launch_histogram(reset: bool = False) -> dict:
+    """{kernel family: launches since the last reset} - which kernels the library's plan really chose (debug / tests)."""
+    n = lib.mcrn_launch_histogram(None, 0, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.mcrn_launch_histogram(buf, n, 1 if reset else 0)
+    return {k: int(v) for k, v in (line.split("=") for line in buf.value.decode().splitlines() if line)}
 
 
 def default_precision() -> int:

@@ -110,6 +110,24 @@ struct Prof {
 };
 static Prof g_prof;
 
+// ---- launch histogram: which kernel FAMILY every planned launch site chose --------------------------------------
+// The plan (plan_model, the *_ok predicates) picks a family by SHAPE; a test case that names a family in its `why` string can ask
+// which ones really launched (mcrn_launch_histogram): tests/test_gpu_parity.py::test_planned_kernel_families_launch fails when a
+// plan edit silently moves a case off the path it was written for.  Host-side counters only (a pointer compare per launch).
+static const int NFAM_MAX = 96;
+static const char* g_fam_name[NFAM_MAX];
+static long long g_fam_n[NFAM_MAX];
+static int g_nfam = 0;
+static inline void fam(const char* name) {
+    for (int i = 0; i < g_nfam; ++i)
+        if (g_fam_name[i] == name || !strcmp(g_fam_name[i], name)) { ++g_fam_n[i]; return; }
+    if (g_nfam < NFAM_MAX) { g_fam_name[g_nfam] = name; g_fam_n[g_nfam++] = 1; }
+}
+static const char* const kFamTiledX3[8] = {"tiled_x3:misc", "tiled_x3:prop", "tiled_x3:wp", "tiled_x3:dgrad", "tiled_x3:propT", "tiled_x3:ds", "tiled_x3:wgrad", "tiled_x3:?"};
+static const char* const kFamTiledF32[8] = {"tiled_f32:misc", "tiled_f32:prop", "tiled_f32:wp", "tiled_f32:dgrad", "tiled_f32:propT", "tiled_f32:ds", "tiled_f32:wgrad", "tiled_f32:?"};
+static const char* const kFamBf16[8] = {"bf16_gemm:misc", "bf16_gemm:prop", "bf16_gemm:wp", "bf16_gemm:dgrad", "bf16_gemm:propT", "bf16_gemm:ds", "bf16_gemm:wgrad", "bf16_gemm:prop_in"};
+static const char* const kFamBf16HiLo[8] = {"bf16_gemm_hilo:misc", "bf16_gemm_hilo:prop", "bf16_gemm_hilo:wp", "bf16_gemm_hilo:dgrad", "bf16_gemm_hilo:propT", "bf16_gemm_hilo:ds", "bf16_gemm_hilo:wgrad", "bf16_gemm_hilo:prop_in"};
+
 // ---- tile-configuration autotuner --------------------------------------------------------------
 // The analytic cost model in choose_cfg() is only a prior: on shapes this small the best tile is
 // decided by latency / occupancy effects it cannot see (measured spread 2x).  In tuning mode
@@ -139,6 +157,7 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
         if (!p.bk_hi[b]) p.bk_hi[b] = p.bk.hi;
     }
     ++g_launches;
+    fam((g_precision == MCRN_BF16X3 ? kFamTiledX3 : kFamTiledF32)[role & 7]);
     const TuneKey key{role, p.M, p.N, p.K, p.nbatch, (int)akc, (int)bkc, g_precision, max_split};
     const int saved_force = g_force_cfg;
     if (g_force_cfg < 0) {
@@ -219,6 +238,7 @@ static inline int gemm(GemmP& p, bool akc, bool bkc, int max_split, int role, hi
     } while (0)
 static inline int prop_small(const PropP& p, int nbatch, int role, double alg, hipStream_t st) {
     const double ex = 2.0 * p.N * (double)p.N * p.ncols * nbatch * p.nseg;
+    fam(role == ROLE_PROPT ? "prop_small:bwd" : "prop_small:fwd");
     MCRN_PROF_WRAP(role, launch_prop_small(p, nbatch, st), ex, alg > 0 ? alg : ex);
     return 0;
 }
@@ -414,7 +434,7 @@ static GemmP gp() {
 
 // ---- bf16-resident GEMM (gemm_bf16.h) with the library's profiling hooks and an on-device tile choice -------
 struct Bf16Key {
-    int btr, M, N, K, nsplit, role;
+    int btr, M, N, K, nsplit, role, nterm;     // (nterm: a key word of its own since round 6 - folded into K, a 3k-deep plain product aliased a k-deep hi/lo one)
     bool operator<(const Bf16Key& o) const { return memcmp(this, &o, sizeof(Bf16Key)) < 0; }
 };
 static std::map<Bf16Key, int> g_tuned_bf16;
@@ -431,7 +451,7 @@ static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8, 0, 0, 0, 0.85, 0.85, 0.85};
     int best = 0; double bt = 1e300;
     for (int c = 0; c < NCFG_BF16; ++c) {
-        if (bf16_cfg_is_sk(c)) continue;
+        if (!bf16_cfg_tuned(c, p.nterm == 3)) continue;
         const int per_cu = kCfgBf16[c][2];
         const long long tiles = (long long)cdiv(p.M, kCfgBf16[c][0]) * cdiv(p.N, kCfgBf16[c][1]) * nsplit;
         const double rounds = ceil((double)tiles / (256.0 * per_cu));
@@ -443,9 +463,12 @@ static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
 static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, hipStream_t st, int prof_role = -1) {
     ++g_launches;
     if (nsplit < 1) nsplit = 1;
+    fam((p.nterm == 3 ? kFamBf16HiLo : kFamBf16)[(prof_role >= 0 ? prof_role : role) & 7]);
     const int nterm_ = p.nterm > 1 ? p.nterm : 1;
-    const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len * nterm_, nsplit, role};
+    const bool x3 = p.nterm == 3;
+    const Bf16Key key{(int)btr, p.M, p.N, p.nseg * p.seg_len, nsplit, role, nterm_};
     int cfg = g_force_cfg_bf16;
+    if (x3 && cfg >= 0 && cfg < NCFG_BF16 && !bf16_cfg_is_sk(cfg) && !bf16_cfg_ok(cfg, true)) cfg = -1;   // (a forced tile the hi/lo form lacks: tuned as usual)
     if (cfg < 0 || cfg >= NCFG_BF16) {
         auto it = g_tuned_bf16.find(key);
         if (it != g_tuned_bf16.end()) cfg = it->second;
@@ -459,7 +482,7 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
             for (int c = 0; c < NCFG_BF16; ++c) cfg_ms[c] = 1e30f;
             for (int round = 0; round < 3; ++round)              // min over 3 rounds of 5 launches: robust to clock / cache noise
                 for (int c = 0; c < NCFG_BF16; ++c) {
-                    if (bf16_cfg_is_sk(c)) continue;
+                    if (!bf16_cfg_tuned(c, x3)) continue;
                     CK(launch_gemm_bf16(p, btr, c, nsplit, role, st));                   // warm-up
                     float ms = 0;
                     if (g_flush) {
@@ -486,9 +509,9 @@ static int bf16_gemm(Bf16GemmP& p, bool btr, int nsplit, int role, double alg, h
                 if (cfg_ms[c] < best_ms) { best_ms = cfg_ms[c]; cfg = c; }
             g_last_tune_ms = best_ms;
             if (getenv("MCRN_TUNE_LOG")) {
-                fprintf(stderr, "[mcrn tune] bf16 %s role %d M=%d N=%d K=%dx%d split=%d:", btr ? "nn" : "nt", role, p.M, p.N, p.nseg,
+                fprintf(stderr, "[mcrn tune] bf16%s %s role %d M=%d N=%d K=%dx%d split=%d:", x3 ? " hi/lo" : "", btr ? "nn" : "nt", role, p.M, p.N, p.nseg,
                         p.seg_len, nsplit);
-                for (int c = 0; c < NCFG_BF16; ++c) if (!bf16_cfg_is_sk(c)) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
+                for (int c = 0; c < NCFG_BF16; ++c) if (bf16_cfg_tuned(c, x3)) fprintf(stderr, " %d:%.1fus", c, 1e3f * cfg_ms[c] / 5.f);
                 fprintf(stderr, " -> %d\n", cfg);
             }
             g_tuned_bf16[key] = cfg;
@@ -519,7 +542,6 @@ static Bf16GemmP bgp(const Sup& u) {
 static inline void x3_terms(Bf16GemmP& p, long long a_lo, long long b_lo) {
     if (g_x3r) { p.nterm = 3; p.a_lo = a_lo; p.b_lo = b_lo; }
 }
-static inline int x3_nterm() { return g_x3r ? 3 : 1; }
 // plane (N x ld fp32) -> bf16 copy (propagation operand) and node-centred bf16 copy (adjacency-gradient operand)
 static int plane_to_bf16(const Shp& s, const Sup& u, const float* X, uint16_t* xb, uint16_t* xc, hipStream_t st);
 static int planes_to_bf16(const Shp& s, const float* X, int np, uint16_t* xb, uint16_t* xc, const float* mu, hipStream_t st,
@@ -593,13 +615,14 @@ static int hoist_inputs(const Shp& s, const Sup& u, float* Z, float* Y, int T, i
     nsplit = nsplit < 1 ? 1 : (nsplit > HOIST_MAX_SPLIT ? HOIST_MAX_SPLIT : nsplit);
     // splits the launcher really makes (bf16_split_plan) for a K tile of 64 and of 32: the consumer below must know the count
     // whatever tile configuration the tuner picks, so a request that the two depths would round differently is not split
-    auto eff = [&](int bk) { const int kt = x3_nterm() * cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk) { const int kt = cdiv(s.N, bk), ns = nsplit > kt ? kt : nsplit; return cdiv(kt, cdiv(kt, ns)); };
     if (eff(64) != eff(32) || bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;    // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64);
     p.slab = (long long)p.M * ncp;
     CKI(bf16_gemm(p, true, nsplit, ROLE_PROP, (double)u.nb * 2.0 * (double)s.N * s.N * (double)ncols, st, PROF_ROLE_PROP_IN));
     if (Xp) {
         const long long rows = (long long)T * u.nb * s.R;
+        fam("hoisted_inputs:compact");
         LAUNCH(k_scatter_compact, dim3(cdiv(rows, 256)), dim3(256), 0, st, (const float*)xin_t, ncp, nsp, p.slab, u.nb, s.N, s.B, w, T, Xp,
                (long long)u.nb * s.R * 4, col0 - s.H, w == s.d ? 1 : 0);
         return 0;
@@ -626,6 +649,7 @@ static int hoist_inputs_small(const Shp& s, const Sup& u, float* Z, float* Y, in
     q.ev0 = q.ev1 = nullptr; q.nunits = q.cps = q.cstride = 0; q.no_d1 = 0;
     q.Sf[0] = u.Sf[0]; q.Sf[1] = u.Sf[1]; q.base = xin_f; q.extra = nullptr; q.PS = t.PS; q.ld = ncp; q.N = s.N; q.ncols = ncp;
     const double fl = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)ncols;
+    fam("prop2_fwd:hoisted_inputs");
     MCRN_PROF_WRAP(ROLE_PROP, launch_prop2_fwd(q, st), fl, fl);
     const long long tot = (long long)4 * s.N * ncols;
     LAUNCH(k_scatter_cols, dim3(cdiv(tot, 256)), dim3(256), 0, st, (const float*)(xin_f + t.PS), ncp, 1, 0LL, 4, s.N, s.B, w, T, Z, Y,
@@ -641,10 +665,10 @@ static const int PROPT_MAX_X = 3;                       // extra partial planes 
 // and of 32: the consumers of the partial planes must know the count whatever tile the tuner picks, so a request is only
 // usable when both depths round it the same way and to itself (-1 otherwise).  want = 2 is exact for every K >= 2 tiles.
 static int bf16_eff_splits(int nseg, int seg_len, int want) {
-    auto eff = [&](int bk) { const int kt = x3_nterm() * nseg * cdiv(seg_len, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk) { const int kt = nseg * cdiv(seg_len, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
     return eff(64) == eff(32) && eff(64) == want ? want : -1;
 }
-struct SplitKey { int role, M, N, K; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
+struct SplitKey { int role, M, N, K, nterm; bool operator<(const SplitKey& o) const { return memcmp(this, &o, sizeof(SplitKey)) < 0; } };
 static std::map<SplitKey, int> g_tuned_split;          // K splits of the transposed propagation, chosen with the tiles
 // hoisted (the packed operand dPb = [nb][Kp][B*H]): only the state channels of plane 0 receive a propagated gradient here;
 // the input channels' share (needed for the go symbol of a step that was not teacher-forced) is go_grad_bf16 below
@@ -670,7 +694,7 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
         // the extra planes dT .. that the element-wise consumers of plane 0 add in a fixed order (no reduction pass, one
         // writer per element).  How many splits fill the chip best depends on the tile the tuner picks: chosen with it.
         p.slab = dT - dP; p.slab2 = s.PS; p.cin_first_only = 1;
-        const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N};
+        const SplitKey key{ROLE_PROPT, p.M, p.N, u.nb * s.N, p.nterm > 1 ? p.nterm : 1};
         // (a request the launcher would round to fewer splits - short K: N <= 64 at cheb_k = 3 - is not taken: the consumers
         //  would add partial planes that nothing wrote; 2 is exact for any K of two tiles or more)
         nsplit = split_env >= 2 && split_env <= 1 + PROPT_MAX_X && bf16_eff_splits(u.nb, s.N, split_env) == split_env ? split_env : 2;
@@ -749,7 +773,7 @@ static int go_grad_bf16(const Shp& s, const Sup& u, const uint16_t* dPin, long l
     nsplit = nsplit < 1 ? 1 : (nsplit > GO_MAX_SPLIT ? GO_MAX_SPLIT : nsplit);
     // splits the launcher really makes for a K tile of 64 and of 32 (bf16_split_plan): the consumer below must know the count
     // whatever tile the tuner picks, so the request is lowered until both depths round it the same way
-    auto eff = [&](int bk, int want) { const int kt = x3_nterm() * u.nb * cdiv(s.N, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
+    auto eff = [&](int bk, int want) { const int kt = u.nb * cdiv(s.N, bk), ns = want > kt ? kt : want; return cdiv(kt, cdiv(kt, ns)); };
     while (nsplit > 1 && eff(64, nsplit) != eff(32, nsplit)) --nsplit;
     if (bf16_cfg_is_sk(g_force_cfg_bf16)) nsplit = 1;                             // (a forced stream-K configuration ignores the split)
     const int nsp = eff(64, nsplit);
@@ -776,6 +800,7 @@ static int prop_fwd(const Shp& s, const Sup& u, float* Z, hipStream_t st, uint16
             alg = 2.0 * 2.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
             ex = alg;
         }
+        fam(s.state_only ? "prop2_fwd:state_only" : (s.N > 256 ? "prop2_fwd:streamed_S" : "prop2_fwd"));
         MCRN_PROF_WRAP_EXT(ROLE_PROP, q, launch_prop2_fwd(q, st), ex, alg);
         return 0;
     }
@@ -912,6 +937,8 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             q.dPb = dPb; q.PSb = s.PSb; dgrad_wrote_bf16 = true;
         }
         const double fl = 2.0 * (double)s.R * O * (double)(s.G * s.Cp);
+        fam(O > 128 ? "dgrad_stream:two_half" : "dgrad_stream");
+        if (q.dPin) fam(q.dPb_lo > 0 ? "dgrad_stream:writes_hilo_operands" : "dgrad_stream:writes_bf16_operands");
         MCRN_PROF_WRAP(ROLE_DGRAD, launch_dgrad_stream(q, st), fl, 2.0 * (double)s.R * O * (double)(s.G * s.C));
     } else {   // d-grad: dP[g][r][c'] = sum_o dY[r][o] Wd[(g,c')][o]
         GemmP p = gp();
@@ -961,6 +988,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             ex = alg = 4.0 * 2.0 * (double)s.N * s.N * (double)s.B * s.H;
         }
         if (ready_attached) q.ev1 = g_side.ready[buf];
+        fam(s.state_only ? "prop2_bwd:state_only" : (s.N > 256 ? "prop2_bwd:streamed_S" : "prop2_bwd"));
         MCRN_PROF_WRAP(ROLE_PROPT, launch_prop2_bwd(q, st), ex, alg);
     } else if (s.K == 3 && small) {
         PropP q;
@@ -1031,6 +1059,7 @@ static int agcn_bwd_core(const Shp& s, const Sup& u, const float* dY, int O, con
             }
             {
                 hipStream_t st = ds_st;   // MCRN_PROF_WRAP records on `st`
+                fam(s.N > 256 ? (u.ds4 ? "ds_wide:four_block" : "ds_wide") : (u.ds4 ? "ds_small:four_block" : (cell_ds ? "ds_small:merged_cell" : "ds_small:per_call")));
                 MCRN_PROF_WRAP(ROLE_DS, launch_ds_small(q, u.nslab, st, nblk), ex, nblk * q.nseg * 2.0 * (double)s.N * s.N * (double)s.B * s.C);
             }
             if (side) {
@@ -1138,6 +1167,7 @@ static int agcn_wgrad(const Shp& s, const float* Xall, long long step_stride, in
         if (T * q.cpt > NSLAB_W) FAIL("weight gradient: %d steps exceed the slab capacity", T);
         *nslab = T * q.cpt;
         const double fl = 2.0 * (double)s.G * s.Cp * O * (double)T * (double)s.R;
+        fam(Xb ? "wgrad_stream:bf16_planes" : "wgrad_stream");
         MCRN_PROF_WRAP(ROLE_WGRAD, launch_wgrad_stream(q, st), fl, 2.0 * (double)s.G * s.C * O * (double)T * (double)s.R);
         return 0;
     }
@@ -1203,6 +1233,7 @@ static int wp_stream(const Shp& s, const Sup& u, const float* Z, const uint16_t*
     q.O = epi == WP_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
     q.out = out; q.out2 = out2; q.out2_ld = out2_ld; q.out2b = out2b; q.hsrc = hsrc; q.hsrc_ld = hsrc_ld; q.zr = zr;
     const double alg = 2.0 * (double)s.R * (2.0 * s.K * s.C) * q.O;
+    fam(Pb ? "wp_stream:bf16_planes" : "wp_stream");
     MCRN_PROF_WRAP(ROLE_WP, launch_wp_stream(q, st), 2.0 * (double)s.R * ((double)s.G * s.H + 16.0) * q.O, alg);
     return 0;
 }
@@ -1275,7 +1306,9 @@ static int cell_bwd_core(const Shp& s, const Sup& u, const float* Z, const float
                       (call0 + 1) * s.B * s.d));
     // (Step B was also built INTO the loader of the gate call's streaming d-grad - one launch less per cell - and measured neutral:
     //  the kernel's 7 us of loads move into the d-grad's serial prologue, six times over; profiles/r5/experiments.md section 5.)
-    if (cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc))
+    const bool vec_b = cell_bwd_vec(s, dP, dTu, Z, zr, dG, dacc);
+    fam(vec_b ? "k_cell_bwd:float4" : "k_cell_bwd:scalar");
+    if (vec_b)
         LAUNCH(k_cell_bwd_b4, dim3(cdiv(RH / 4, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
     else
     LAUNCH(k_cell_bwd_b, dim3(cdiv(RH, 256)), dim3(256), 0, st, (const float*)dP, (const float*)dTu, xu, s.PS, (long long)s.Cp, Z, (long long)s.Cp, zr, s.H, s.R, dG, dacc);
@@ -1483,9 +1516,11 @@ static int wunprep(float* dW, const float* slabs, const Shp& s, int O, hipStream
     const long long slab = (long long)(s.G * s.Cp + (dbias ? 1 : 0)) * O;
     // four outputs per thread when every 4-group stays inside one row of both layouts and every address is 16-byte aligned
     if ((O & 3) == 0 && (slab & 3) == 0 && (((uintptr_t)dW | (uintptr_t)slabs | (uintptr_t)dbias) & 15) == 0) {
+        fam("k_wunprep:float4");
         LAUNCH(k_wunprep4, dim3(cdiv(tot, 256)), dim3(1024), 0, st, dW, slabs, nslab, slab, s.d, s.H, s.Cp, s.K, O, dbias);
         return 0;
     }
+    fam("k_wunprep:scalar");
     LAUNCH(k_wunprep, dim3(cdiv(tot, 64)), dim3(1024), 0, st, dW, slabs, nslab, slab, s.d, s.H, s.Cp, s.K, O, dbias);
     return 0;
 }
@@ -2410,11 +2445,26 @@ using namespace mcrn;
 // =================================================================================================
 // C ABI
 // =================================================================================================
+#pragma GCC visibility push(default)   // (-fvisibility=hidden: only the C ABI is exported)
 extern "C" {
 
 const char* mcrn_last_error(void) { return g_err; }
-int mcrn_version(void) { return 105; }
+int mcrn_version(void) { return 106; }
+#ifndef MCRN_BUILD_ID
+#define MCRN_BUILD_ID "unknown"
+#endif
+const char* mcrn_build_id(void) { return MCRN_BUILD_ID; }
 int mcrn_last_launch_count(void) { return g_launches; }
+// launch histogram (see fam()): "family=count\n" lines, NUL-terminated; returns the bytes needed (incl. the NUL).  reset = 1 clears it.
+long long mcrn_launch_histogram(char* buf, long long cap, int reset) {
+    static char out[NFAM_MAX * 96];
+    size_t n = 0;
+    for (int i = 0; i < g_nfam && n + 96 < sizeof out; ++i) n += (size_t)snprintf(out + n, 96, "%s=%lld\n", g_fam_name[i], g_fam_n[i]);
+    out[n++] = 0;
+    if (buf && cap >= (long long)n) memcpy(buf, out, n);
+    if (reset) g_nfam = 0;
+    return (long long)n;
+}
 
 int mcrn_set_gemm_cfg(int cfg) {
     if (cfg < -1 || cfg >= NCFG) FAIL("gemm cfg %d outside -1..%d", cfg, NCFG - 1);
@@ -2468,7 +2518,7 @@ int mcrn_model_autotune(const mcrn_dims_t* d, void* ws, size_t ws_bytes, void* s
     mcrn_grads_t G = {gg[0], gg[1], gg[2], gg[3], gg[4], gg[5], gg[6], gg[7], gg[8], gg[9], gg[10], gg[11], gg[12], gg[13]};
     PrecisionScope prec(d->precision);
     g_tuning = true;
-    if (d->precision == MCRN_BF16) {
+    if (d->precision == MCRN_BF16 || (d->precision == MCRN_BF16X3 && d->N > PROP2_MAX_N)) {   // (the sessions that run gemm_bf16.h products)
         g_flush_bytes = (size_t)192 << 20;
         if (hipMalloc(&g_flush, g_flush_bytes) != hipSuccess) { g_flush = nullptr; g_flush_bytes = 0; (void)hipGetLastError(); }
     }
@@ -2531,7 +2581,9 @@ int mcrn_autotune_import(const int* buf, long long n) {
         } else if (kind == 1) {
             if (cfg < 0 || cfg >= NCFG_BF16) FAIL("autotune_import: bf16 tile configuration %d out of range", cfg);
             if (bf16_cfg_is_sk(cfg)) FAIL("autotune_import: tile configuration %d is a retired slot", cfg);
-            Bf16Key k; memcpy(&k, buf + i + 2, sizeof k); b[k] = cfg;
+            Bf16Key k; memcpy(&k, buf + i + 2, sizeof k);
+            if (!bf16_cfg_ok(cfg, k.nterm == 3)) FAIL("autotune_import: tile configuration %d has no hi/lo form", cfg);
+            b[k] = cfg;
         } else {
             if (cfg < 1 || cfg > 1 + PROPT_MAX_X) FAIL("autotune_import: split count %d out of range", cfg);
             SplitKey k; memcpy(&k, buf + i + 2, sizeof k); c[k] = cfg;
@@ -2907,3 +2959,4 @@ int mcrn_gemm_f32(int M, int N, int K, int transA, int transB, const float* A, c
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

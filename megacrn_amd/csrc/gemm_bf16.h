@@ -74,13 +74,23 @@ __device__ unsigned long long g_bf16_clk[4];
 #endif
 
 // ---- pieces shared by the two kernels ------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NT, bool BTR>
+// X3 (round 6): hi/lo operand PAIRS (Bf16GemmP::nterm == 3: the lo copies sit a_lo / b_lo elements behind the hi ones).  A K tile is FOUR
+// images - A_hi, A_lo, B_hi, B_lo - fetched ONCE each, and the three MFMA blocks
+//     A_hi x B_hi + A_hi x B_lo + A_lo x B_hi
+// are issued from LDS: the bf16x3 arithmetic of the library (fp32 operands as bf16 hi + lo, fp32 accumulate, ~4e-6) on bf16-RESIDENT
+// operands with 4 tile fetches and 0.5 fragment reads per MFMA.  (Round 5 walked every K segment three times with a full A + B fetch per
+// term: 6 fetches where 4 distinct tiles exist, 2.78 x the algorithmic bytes through the fabric ports at N = 1843.)
+template <int BM, int BN, int BK, int NT, bool BTR, bool X3 = false>
 struct Bf16Tile {
     static constexpr int CH = BK / 8, RP = 16 / CH, KS = BK / 16;
-    static constexpr int ASLOTS = BM * CH, BSLOTS = BN * CH;            // 16-byte chunks per tile
+    static constexpr int ASLOTS = BM * CH, BSLOTS = BN * CH;            // 16-byte chunks per tile image
     static constexpr int AJ = (ASLOTS + NT - 1) / NT, BJ = (BSLOTS + NT - 1) / NT;
-    static constexpr int NLD_MIN = ASLOTS / NT + BSLOTS / NT;           // DMA instructions every wave issues per tile
-    static constexpr int STAGE = (ASLOTS + BSLOTS) * 16;                // bytes
+    static constexpr int NOP = X3 ? 2 : 1;                              // images per operand: hi (+ lo)
+    static constexpr int NTM = X3 ? 3 : 1;                              // MFMA terms per fragment pair
+    static constexpr int NLD_MIN = NOP * (ASLOTS / NT + BSLOTS / NT);   // DMA instructions every wave issues per tile
+    static constexpr int A_IMG = ASLOTS * 16, B_IMG = BSLOTS * 16;      // bytes of one image
+    static constexpr int B_OFF = NOP * A_IMG;                           // stage layout: [A_hi | A_lo | B_hi | B_lo]
+    static constexpr int STAGE = NOP * (A_IMG + B_IMG);                 // bytes
     static_assert(ASLOTS % 64 == 0 && BSLOTS % 64 == 0, "whole waves per pass");
     static_assert(BK == 32 || BK == 64, "BK");
 
@@ -89,11 +99,7 @@ struct Bf16Tile {
     long long stepA_seg, stepB_seg, stepB_k;   // scalar strides (elements)
     int tps;
     int iss_seg, iss_lt;                  // K tile the next DMA will fetch
-    // hi/lo operand pairs (Bf16GemmP::nterm == 3, round 5): every K segment is walked three times,
-    //   term 0: A_hi x B_hi    term 1: A_hi x B_lo    term 2: A_lo x B_hi        (lo copies a_lo / b_lo elements behind the hi ones)
-    // = the bf16x3 arithmetic of the library (fp32 operands as bf16 hi + lo, fp32 accumulate, ~1e-5) on bf16-RESIDENT operands
-    int nterm, iss_term;
-    long long a_lo, b_lo;
+    long long a_lo, b_lo;                 // X3: element offsets of the lo images
 
     // (Every workgroup walks its K tiles IN ORDER.  Round 5 tried a per-tile rotated start - workgroups that share an operand panel on one
     //  XCD would then not ask for the same lines at the same time - and measured 20 - 25 % SLOWER on every product, harness and model: the
@@ -135,48 +141,41 @@ struct Bf16Tile {
             stepB_k = 1;
         }
         stepA_seg = p.a_seg; stepB_seg = p.b_seg; tps = p.tps;
-        nterm = p.nterm > 1 ? p.nterm : 1; a_lo = p.a_lo; b_lo = p.b_lo;
-        const int per = nterm * p.tps;                    // K tiles of one segment (all its terms)
-        iss_seg = kt_beg / per;
-        const int r = kt_beg - iss_seg * per;
-        iss_term = r / p.tps; iss_lt = r - iss_term * p.tps;
+        a_lo = p.a_lo; b_lo = p.b_lo;
+        iss_seg = kt_beg / p.tps;
+        iss_lt = kt_beg - iss_seg * p.tps;
     }
     __device__ __forceinline__ void advance() {
-        if (++iss_lt == tps) { iss_lt = 0; if (++iss_term == nterm) { iss_term = 0; ++iss_seg; } }
+        if (++iss_lt == tps) { iss_lt = 0; ++iss_seg; }
     }
     // DMA of the next K tile into LDS stage `stg`
     __device__ __forceinline__ void issue(unsigned lds_base, int stg, int wave) {
-        const uint16_t* __restrict__ Ab = baseA + (long long)iss_seg * stepA_seg + (iss_term == 2 ? a_lo : 0LL) + iss_lt * BK;
-        const uint16_t* __restrict__ Bb = baseB + (long long)iss_seg * stepB_seg + (iss_term == 1 ? b_lo : 0LL) + (long long)(iss_lt * BK) * stepB_k;
-        const unsigned sA = lds_base + stg * STAGE + wave * 1024;
-        const unsigned sB = sA + ASLOTS * 16;
+        issue_begin(lds_base, stg, wave);
 #pragma unroll
-        for (int j = 0; j < AJ; ++j)
-            if (ASLOTS % NT == 0 || j * NT + wave * 64 < ASLOTS) glds16(Ab, offA[j], sA + j * NT * 16);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(Bb, offB[j], sB + j * NT * 16);
-        advance();
+        for (int J = 0; J < NPIECE; ++J) issue_piece(J, wave);
+        issue_end();
     }
     // The same DMA in PIECES, for K loops that slip them between the MFMAs of the tile being multiplied: a wave that issues
     // its 6 - 8 pieces back to back waits 60 - 180 cycles per piece for the address path with the matrix pipe idle
     // (profiles/r4/experiments.md section 13: the loop without its DMA ran 12 - 14 % faster); one piece every few MFMAs
     // issues in the shadow of the 32-cycle MFMA in flight.   issue_begin ; issue_piece(0 .. NPIECE-1) ; issue_end
-    static constexpr int NPIECE = AJ + BJ;
+    // piece order: A_hi pieces, (X3: A_lo pieces,) B_hi pieces, (X3: B_lo pieces)
+    static constexpr int NPIECE = NOP * (AJ + BJ);
     const uint16_t *pcA, *pcB;
     unsigned pcsA, pcsB;
     __device__ __forceinline__ void issue_begin(unsigned lds_base, int stg, int wave) {
-        pcA = baseA + (long long)iss_seg * stepA_seg + (iss_term == 2 ? a_lo : 0LL) + iss_lt * BK;
-        pcB = baseB + (long long)iss_seg * stepB_seg + (iss_term == 1 ? b_lo : 0LL) + (long long)(iss_lt * BK) * stepB_k;
+        pcA = baseA + (long long)iss_seg * stepA_seg + iss_lt * BK;
+        pcB = baseB + (long long)iss_seg * stepB_seg + (long long)(iss_lt * BK) * stepB_k;
         pcsA = lds_base + stg * STAGE + wave * 1024;
-        pcsB = pcsA + ASLOTS * 16;
+        pcsB = pcsA + B_OFF;
     }
     __device__ __forceinline__ void issue_piece(int J, int wave) {          // J is a constant after unrolling
-        if (J < AJ) {
-            if (ASLOTS % NT == 0 || J * NT + wave * 64 < ASLOTS) glds16(pcA, offA[J], pcsA + J * NT * 16);
-        } else if (J < AJ + BJ) {
-            const int j = J - AJ;
-            if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(pcB, offB[j], pcsB + j * NT * 16);
+        if (J < NOP * AJ) {
+            const int img = J / AJ, j = J - img * AJ;
+            if (ASLOTS % NT == 0 || j * NT + wave * 64 < ASLOTS) glds16(img ? pcA + a_lo : pcA, offA[j], pcsA + img * A_IMG + j * NT * 16);
+        } else if (J < NPIECE) {
+            const int q = J - NOP * AJ, img = q / BJ, j = q - img * BJ;
+            if (BSLOTS % NT == 0 || j * NT + wave * 64 < BSLOTS) glds16(img ? pcB + b_lo : pcB, offB[j], pcsB + img * B_IMG + j * NT * 16);
         }
     }
     __device__ __forceinline__ void issue_end() { advance(); }
@@ -413,11 +412,12 @@ __device__ __forceinline__ void bf16_epilogue(const Bf16GemmP& p, f32x16_t (&acc
 // ---------------------------------------------------------------------------------------------------------
 // (ROLE only changes the symbol name, so that rocprofv3 reports the forward propagation, its transpose and the
 //  adjacency gradient separately: 1 / 4 / 5 as in gemm_f32.h, 0 = everything else)
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16GemmP p) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
-    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
+    using T = Bf16Tile<BM, BN, BK, NT, BTR, X3>;
+    constexpr int NOP = T::NOP, NTM = T::NTM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     int split;
     bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
+    const int nkt = p.nseg * p.tps;
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
     if (kt_beg >= kt_end) return;
@@ -455,8 +455,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         if (s < nt) tl.issue(lds_base, s, wave);
     int rd = 0;
 #if MCRN_BF16_ABL & 2
-    bf16x8_t a[2][FM], b[2][FN];
+    bf16x8_t a[2][NOP][FM], b[2][NOP][FN];
 #endif
+    // MFMA term tm of a fragment pair: 0 = hi x hi ; X3: 1 = hi x lo, 2 = lo x hi
     for (int t = 0; t < nt; ++t) {
         // tile t has landed once at most the DMA of the NSTAGE-2 younger tiles remains in flight (steady state);
         // in the tail fewer tiles are in flight: drain
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         else MCRN_VMCNT(0);
         __syncthreads();                                         // tile t visible to all; tile t-1 consumed by all
         const unsigned char* sA = smem_bf16 + rd * T::STAGE;
-        const unsigned char* sB = sA + T::ASLOTS * 16;
+        const unsigned char* sB = sA + T::B_OFF;
         // Wave tiles of 8+ fragments (128 x 64): the DMA pieces go BETWEEN the MFMAs (see Bf16Tile::issue_piece; -5 .. -8 % per
         // launch).  The 64 x 64 wave tile of the 256 x 128 eight-wave form has only 16 MFMAs per tile for 6 pieces and two
         // waves per SIMD already overlap each other's issue: it keeps the DMA behind its MFMAs (interleaved: +1 %).
@@ -472,18 +473,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         if constexpr (!ILV) {
 #pragma unroll
             for (int ks = 0; ks < T::KS; ++ks) {
-                bf16x8_t a1[FM], b1[FN];
+                bf16x8_t a1[NOP][FM], b1[NOP][FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i) a1[i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+                for (int o = 0; o < NOP; ++o) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) b1[j] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+                    for (int i = 0; i < FM; ++i) a1[o][i] = *reinterpret_cast<const bf16x8_t*>(sA + o * T::A_IMG + (aoff[i] ^ (ks << 5)));
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                    for (int j = 0; j < FN; ++j) b1[o][j] = bf16_read_b<BN, BTR>(sB + o * T::B_IMG, boff[j], ks);
+                }
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(a1[i]), "v"(b1[j])); }
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                    }
+                for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            const bf16x8_t& av = a1[tm == 2 ? 1 : 0][i];
+                            const bf16x8_t& bv = b1[tm == 1 ? 1 : 0][j];
+                            if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(av), "v"(bv)); }
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                        }
             }
             if (!(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt) {
                 int wr = rd + NSTAGE - 1;
@@ -499,42 +507,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
                 if (wr >= NSTAGE) wr -= NSTAGE;
                 tl.issue_begin(lds_base, wr, wave);
             }
-            constexpr int NM = T::KS * FM * FN;
+            constexpr int NM = T::KS * NTM * FM * FN;
             static_assert(T::NPIECE <= NM, "at most one DMA piece per MFMA");
             // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks (two register sets)
 #if MCRN_BF16_ABL & 2
             if (t == 0) {
 #else
-            bf16x8_t a[2][FM], b[2][FN];
+            bf16x8_t a[2][NOP][FM], b[2][NOP][FN];
             {
 #endif
 #pragma unroll
-                for (int i = 0; i < FM; ++i) a[0][i] = *reinterpret_cast<const bf16x8_t*>(sA + aoff[i]);
+                for (int o = 0; o < NOP; ++o) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) b[0][j] = bf16_read_b<BN, BTR>(sB, boff[j], 0);
+                    for (int i = 0; i < FM; ++i) a[0][o][i] = *reinterpret_cast<const bf16x8_t*>(sA + o * T::A_IMG + aoff[i]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) b[0][o][j] = bf16_read_b<BN, BTR>(sB + o * T::B_IMG, boff[j], 0);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < T::KS; ++ks) {
                 const int cur = (MCRN_BF16_ABL & 2) ? 0 : (ks & 1), nxt = cur ^ 1;
                 if (!(MCRN_BF16_ABL & 2) && ks + 1 < T::KS) {
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) a[nxt][i] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ ((ks + 1) << 5)));
+                    for (int o = 0; o < NOP; ++o) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) b[nxt][j] = bf16_read_b<BN, BTR>(sB, boff[j], ks + 1);
+                        for (int i = 0; i < FM; ++i) a[nxt][o][i] = *reinterpret_cast<const bf16x8_t*>(sA + o * T::A_IMG + (aoff[i] ^ ((ks + 1) << 5)));
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) b[nxt][o][j] = bf16_read_b<BN, BTR>(sB + o * T::B_IMG, boff[j], ks + 1);
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(a[cur][i]), "v"(b[cur][j])); }
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-                        const int q = bf16_piece_after((ks * FM + i) * FN + j, NM, T::NPIECE);
-                        if (q >= 0) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (refill) tl.issue_piece(q, wave);
-                            __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            const bf16x8_t& av = a[cur][tm == 2 ? 1 : 0][i];
+                            const bf16x8_t& bv = b[cur][tm == 1 ? 1 : 0][j];
+                            if (MCRN_BF16_ABL & 4) { asm volatile("" ::"v"(av), "v"(bv)); }
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                            const int q = bf16_piece_after(((ks * NTM + tm) * FM + i) * FN + j, NM, T::NPIECE);
+                            if (q >= 0) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (refill) tl.issue_piece(q, wave);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
-                    }
             }
             if (refill) tl.issue_end();
         }
@@ -556,13 +574,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
 //     phase 2t+1 : G0 compute(t) | G1 load(t)           released by the barrier that ended phase 2t-1)
 // and waits (counted vmcnt) for its share of tile t+1 before the barrier that ends phase 2t+1.
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NSTAGE, bool BTR>
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, bool X3 = false>
 struct PpLoop {
     static constexpr int WGM = 2, WGN = 4, NT = 512;
     static constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
     static_assert(BM % 64 == 0 && BN % 128 == 0, "tile shape");
-    using T = Bf16Tile<BM, BN, BK, NT, BTR>;
-    static constexpr int KS = T::KS;
+    using T = Bf16Tile<BM, BN, BK, NT, BTR, X3>;
+    static constexpr int KS = T::KS, NOP = T::NOP, NTM = T::NTM;
 
     // acc = sum over the K tiles [kt_beg, kt_beg + nt) of the C tile at (m_blk, n_blk).  Ends with every fragment in
     // registers; the caller puts a barrier between the use of acc and the next run() (LDS stages are reused).
@@ -579,52 +597,60 @@ struct PpLoop {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-        bf16x8_t fa[FM][KS], fb[FN][KS];
+        bf16x8_t fa[NOP][FM][KS], fb[NOP][FN][KS];
         bool first_load = true;
         auto load_frags = [&](int stg) {
             if ((MCRN_BF16_ABL & 2) && !first_load) return;
             first_load = false;
             const unsigned char* sA = smem + stg * T::STAGE;
-            const unsigned char* sB = sA + T::ASLOTS * 16;
+            const unsigned char* sB = sA + T::B_OFF;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < FM; ++i) fa[i][ks] = *reinterpret_cast<const bf16x8_t*>(sA + (aoff[i] ^ (ks << 5)));
+                for (int o = 0; o < NOP; ++o) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) fb[j][ks] = bf16_read_b<BN, BTR>(sB, boff[j], ks);
+                    for (int i = 0; i < FM; ++i) fa[o][i][ks] = *reinterpret_cast<const bf16x8_t*>(sA + o * T::A_IMG + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) fb[o][j][ks] = bf16_read_b<BN, BTR>(sB + o * T::B_IMG, boff[j], ks);
+                }
             }
         };
-        constexpr int NM = KS * FM * FN;
+        constexpr int NM = KS * NTM * FM * FN;
         static_assert(T::NPIECE <= NM, "at most one DMA piece per MFMA");
         // dma_tag: std::true_type = the pieces of the tile opened with issue_begin go between the MFMAs (when `refill`)
         auto compute = [&](auto dma_tag, bool refill) {
             if (MCRN_BF16_ABL & 4) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(fa[i][ks]));
+                    for (int o = 0; o < NOP; ++o) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(fb[j][ks]));
-                }
+                        for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(fa[o][i][ks]));
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(fb[o][j][ks]));
+                    }
                 return;
             }
             __builtin_amdgcn_s_setprio(1);
+            // term tm of a fragment pair: 0 = hi x hi ; X3: 1 = hi x lo, 2 = lo x hi (FM * FN independent MFMAs between two on one accumulator)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
-                        if constexpr (decltype(dma_tag)::value) {
-                            const int q = bf16_piece_after((ks * FM + i) * FN + j, NM, T::NPIECE);
-                            if (q >= 0) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                if (refill) tl.issue_piece(q, wave);
-                                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm == 2 ? 1 : 0][i][ks], fb[tm == 1 ? 1 : 0][j][ks], acc[i][j], 0, 0, 0);
+                            if constexpr (decltype(dma_tag)::value) {
+                                const int q = bf16_piece_after(((ks * NTM + tm) * FM + i) * FN + j, NM, T::NPIECE);
+                                if (q >= 0) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (refill) tl.issue_piece(q, wave);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
                             }
                         }
-                    }
             __builtin_amdgcn_s_setprio(0);
         };
         // wait until this wave's share of tile u has landed: issued so far are tiles <= u + NSTAGE - 2
@@ -678,9 +704,9 @@ struct PpLoop {
     }
 };
 
-template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
-    using L = PpLoop<BM, BN, BK, NSTAGE, BTR>;
+    using L = PpLoop<BM, BN, BK, NSTAGE, BTR, X3>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -690,7 +716,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     int split;
     bf16_tile_of(p, BM, BN, tile_m, tile_n, split);
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
+    const int nkt = p.nseg * p.tps;
     const int kt_beg = split * p.tiles_per_split;
     const int kt_end = min(nkt, kt_beg + p.tiles_per_split);
     if (kt_beg >= kt_end) return;
@@ -713,80 +739,124 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
 // ---- host side ----------------------------------------------------------------------------------
 static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
     p.tps = (p.seg_len + BK - 1) / BK;
-    const int nkt = p.nseg * p.tps * (p.nterm > 1 ? p.nterm : 1);
+    const int nkt = p.nseg * p.tps;                   // (hi/lo pairs: the three terms of a K tile are ONE tile of the walk)
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nkt) nsplit = nkt;
     p.tiles_per_split = (nkt + nsplit - 1) / nsplit;
     p.nsplit = (nkt + p.tiles_per_split - 1) / p.tiles_per_split;
 }
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE, bool X3 = false>
 static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st) {
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16 * (X3 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE, X3>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     (void)hipGetLastError();
     if (p.ev0 && p.ev1)
-        hipExtLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st,
+        hipExtLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE, X3>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st,
                               (hipEvent_t)p.ev0, (hipEvent_t)p.ev1, 0, p);
     else
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, BK, NSTAGE, BTR, ROLE, X3>), dim3(tiles * p.nsplit), dim3(64 * WGM * WGN), lds, st, p);
     return hipGetLastError();
 }
-template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE>
+template <int BM, int BN, int BK, int NSTAGE, bool BTR, int ROLE, bool X3 = false>
 static inline hipError_t launch_one_bf16_pp(Bf16GemmP p, int nsplit, hipStream_t st) {
     p.cin_pre = 0;                                   // the ping-pong kernel keeps the read-modify-write epilogue (register budget, see the kernel)
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16 * (X3 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE, X3>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     (void)hipGetLastError();
     if (p.ev0 && p.ev1)
-        hipExtLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st,
+        hipExtLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE, X3>), dim3(tiles * p.nsplit), dim3(512), lds, st,
                               (hipEvent_t)p.ev0, (hipEvent_t)p.ev1, 0, p);
     else
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE>), dim3(tiles * p.nsplit), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, BK, NSTAGE, BTR, ROLE, X3>), dim3(tiles * p.nsplit), dim3(512), lds, st, p);
     return hipGetLastError();
 }
+// Translation units: the plain and the hi/lo kernels compile separately (gemm_bf16_unit.hip: MCRN_BF16_PART 1, gemm_bf16_x3_unit.hip: 2;
+// ~2.5 min each); the stand-alone harness includes both (0).
+#ifndef MCRN_BF16_PART
+#define MCRN_BF16_PART 0
+#endif
+// harness builds only (tools/kbench, -DMCRN_BF16_CFGMASK=bits): instantiate just these tile slots (a one-slot A/B build compiles in seconds)
+#ifndef MCRN_BF16_CFGMASK
+#define MCRN_BF16_CFGMASK 0xFFFF
+#endif
+#define MCRN_CFG_ON(n) if constexpr (!(((MCRN_BF16_CFGMASK) >> (n)) & 1)) return hipErrorInvalidValue; else
+hipError_t launch_gemm_bf16_hilo(const Bf16GemmP& p, bool btr, int cfg, int nsplit, int role, hipStream_t st);
+#if MCRN_BF16_PART != 2
 template <bool BTR, int ROLE>
 static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
-        case 0: return launch_one_bf16<128, 128, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);   //  64 KB   2
-        case 1: return launch_one_bf16<256, 128, 4, 2, 64, 3, BTR, ROLE>(p, nsplit, st);   // 144 KB   1
-        case 2: return launch_one_bf16<256, 256, 2, 4, 64, 2, BTR, ROLE>(p, nsplit, st);   // 128 KB   1
-        case 3: return launch_one_bf16_pp<256, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong
-        case 4: return launch_one_bf16_pp<256, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong, 64-deep phases
-        case 5: return launch_one_bf16_pp<320, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 144 KB   1   ping-pong
-        case 6: return launch_one_bf16_pp<192, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong
-        case 7: return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
-        case 8: return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
-        case 9: return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
+        case 0: MCRN_CFG_ON(0) return launch_one_bf16<128, 128, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);   //  64 KB   2
+        case 1: MCRN_CFG_ON(1) return launch_one_bf16<256, 128, 4, 2, 64, 3, BTR, ROLE>(p, nsplit, st);   // 144 KB   1
+        case 2: MCRN_CFG_ON(2) return launch_one_bf16<256, 256, 2, 4, 64, 2, BTR, ROLE>(p, nsplit, st);   // 128 KB   1
+        case 3: MCRN_CFG_ON(3) return launch_one_bf16_pp<256, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong
+        case 4: MCRN_CFG_ON(4) return launch_one_bf16_pp<256, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 128 KB   1   ping-pong, 64-deep phases
+        case 5: MCRN_CFG_ON(5) return launch_one_bf16_pp<320, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 144 KB   1   ping-pong
+        case 6: MCRN_CFG_ON(6) return launch_one_bf16_pp<192, 256, 32, 4, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong
+        case 7: MCRN_CFG_ON(7) return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 8: MCRN_CFG_ON(8) return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
+        case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
         case 10: case 11: case 12: return hipErrorInvalidValue;                           // retired slots (round 2's stream-K tiles, removed in round 5)
         // FOUR waves (one per SIMD), 128 x 64 wave tiles: a 32K-output tile - the size that fills 256 CUs in one round on
         // the hoisted N = 1843 encoder product (7372 x 1024: 232 tiles) - read with 0.75 LDS fragment reads per MFMA, like
         // the 256 x 256 eight-wave tile (the eight-wave 256 x 128 forms have 64 x 64 or 128 x 32 wave tiles: 1.0 / 1.25)
-        case 13: return launch_one_bf16<256, 128, 2, 2, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
-        case 14: return launch_one_bf16<128, 256, 1, 4, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
-        default: return launch_one_bf16<256, 192, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);  // 112 KB   1   128 x 96 wave tiles
+        case 13: MCRN_CFG_ON(13) return launch_one_bf16<256, 128, 2, 2, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
+        case 14: MCRN_CFG_ON(14) return launch_one_bf16<128, 256, 1, 4, 64, 3, BTR, ROLE>(p, nsplit, st);  // 144 KB   1
+        default: MCRN_CFG_ON(15) return launch_one_bf16<256, 192, 2, 2, 64, 2, BTR, ROLE>(p, nsplit, st);  // 112 KB   1   128 x 96 wave tiles
     }
 }
+#endif
+#if MCRN_BF16_PART != 1
+// hi/lo operand pairs (nterm == 3): the same tile shapes, every K tile 32 deep and FOUR images wide (A_hi, A_lo, B_hi, B_lo), so a stage
+// holds as many bytes as a 64-deep plain tile.  Slots whose plain form differs only in depth / stage count share a kernel (kCfgBf16X3Alias:
+// the tuner skips the duplicates); 320 x 256 does not fit the register file with two operand images.
+template <bool BTR, int ROLE>
+static inline hipError_t launch_cfg_bf16_x3(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
+    switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
+        case 0: MCRN_CFG_ON(0) return launch_one_bf16<128, 128, 2, 2, 32, 2, BTR, ROLE, true>(p, nsplit, st);   //  64 KB   2
+        case 1: MCRN_CFG_ON(1) return launch_one_bf16<256, 128, 4, 2, 32, 3, BTR, ROLE, true>(p, nsplit, st);   // 144 KB   1
+        case 2: MCRN_CFG_ON(2) return launch_one_bf16<256, 256, 2, 4, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 128 KB   1
+        case 3: case 4: MCRN_CFG_ON(3) return launch_one_bf16_pp<256, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 128 KB   1   ping-pong
+        case 6: case 8: MCRN_CFG_ON(6) return launch_one_bf16_pp<192, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 112 KB   1   ping-pong
+        case 7: MCRN_CFG_ON(7) return launch_one_bf16_pp<256, 128, 32, 3, BTR, ROLE, true>(p, nsplit, st);      // 144 KB   1   ping-pong
+        case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 32, 2, BTR, ROLE, true>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 13: MCRN_CFG_ON(13) return launch_one_bf16<256, 128, 2, 2, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
+        case 14: MCRN_CFG_ON(14) return launch_one_bf16<128, 256, 1, 4, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
+        case 15: MCRN_CFG_ON(15) return launch_one_bf16<256, 192, 2, 2, 32, 2, BTR, ROLE, true>(p, nsplit, st);  // 112 KB   1
+        default: return hipErrorInvalidValue;                                              // 5 (320 x 256), retired slots
+    }
+}
+hipError_t launch_gemm_bf16_hilo(const Bf16GemmP& p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {
+    // each hot role uses one storage form of B; everything else is "misc"
+    if (role == 1 && btr) return launch_cfg_bf16_x3<true, 1>(p, cfg, nsplit, st);
+    if (role == 4 && btr) return launch_cfg_bf16_x3<true, 4>(p, cfg, nsplit, st);
+    if (role == 5 && !btr) return launch_cfg_bf16_x3<false, 5>(p, cfg, nsplit, st);
+    return btr ? launch_cfg_bf16_x3<true, 0>(p, cfg, nsplit, st) : launch_cfg_bf16_x3<false, 0>(p, cfg, nsplit, st);
+}
+#endif
+#if MCRN_BF16_PART != 2
 hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.seg_len <= 0) return hipSuccess;
     if (p.nterm != 0 && p.nterm != 1 && p.nterm != 3) return hipErrorInvalidValue;
+    const bool x3 = p.nterm == 3;
+    if (!bf16_cfg_ok(cfg, x3)) return hipErrorInvalidValue;
     // stacked outputs whose blocks are contiguous ((r / inner) * hi + (r % inner) * lo with hi == inner * lo) are plain rows
     if (p.cm.inner > 0 && p.cm.hi == (long long)p.cm.inner * p.cm.lo) p.cm = rm_plain(p.cm.lo);
     if (p.cbm.inner > 0 && p.cbm.hi == (long long)p.cbm.inner * p.cbm.lo) p.cbm = rm_plain(p.cbm.lo);
@@ -800,10 +870,12 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
     if (p.cin_pre && !(p.Cin && p.C && p.alpha == 1.f && p.beta == 1.f && (p.nsplit <= 1 || p.cin_first_only) && (nsplit <= 1 || p.cin_first_only)))
         return hipErrorInvalidValue;                                    // (the preload IS the addend: no scaling, split 0 only)
     // each hot role uses one storage form of B; everything else is "misc"
+    if (x3) return launch_gemm_bf16_hilo(p, btr, cfg, nsplit, role, st);
     if (role == 1 && btr) return launch_cfg_bf16<true, 1>(p, cfg, nsplit, st);
     if (role == 4 && btr) return launch_cfg_bf16<true, 4>(p, cfg, nsplit, st);
     if (role == 5 && !btr) return launch_cfg_bf16<false, 5>(p, cfg, nsplit, st);
     return btr ? launch_cfg_bf16<true, 0>(p, cfg, nsplit, st) : launch_cfg_bf16<false, 0>(p, cfg, nsplit, st);
 }
+#endif
 
 }  // namespace mcrn

@@ -26,6 +26,71 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.mcrn_version() >= 100
 
 
+def test_library_exports_only_the_c_abi():
+    """-fvisibility=hidden (round 6): every exported FUNCTION is one the header declares; nothing of namespace mcrn's host code
+    is in the dynamic symbol table (HIP's kernel-handle data objects are, by construction of the runtime's registration)."""
+    import shutil
+    import subprocess
+    from megacrn_amd import _lib
+    nm = shutil.which("nm")
+    if not nm:
+        pytest.skip("nm not present")
+    hdr = open(os.path.join(ROOT, "include", "megacrn_hip.h")).read()
+    declared = set(re.findall(r"\b(mcrn_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtWw"}
+    funcs -= {"_init", "_fini"}
+    exported_host_code = sorted(f for f in funcs if f.startswith("_Z"))
+    assert not exported_host_code, exported_host_code[:5]
+    assert {f for f in funcs if f.startswith("mcrn_")} == declared, sorted(declared ^ {f for f in funcs if f.startswith("mcrn_")})
+
+
+def test_build_id_ties_measured_artefacts_to_the_library(tmp_path, monkeypatch):
+    """the PMC traffic table bench.py reports must belong to the library that ran.  A table measured on
+    another build (a deliberately stale file) makes `traffic` / `step_fabric_*` disappear; the newest profiles/r<NN>/ wins."""
+    import json
+    import bench
+    from megacrn_amd import _lib
+    bid = _lib.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", bid), bid
+    prof = tmp_path / "profiles"
+    (prof / "r7").mkdir(parents=True)
+    (prof / "r12").mkdir()
+    table = {"prop2_fwd_kernel<7, 2>": {"launches": 24, "hbm_bytes_per_launch_corrected": 3.0e7},
+             "k_clip_adam": {"launches": 1, "hbm_bytes_per_launch_corrected": 1.0e6},
+             "_step": {"fabric_bytes": 1.5e10, "dispatches": 358}}
+    json.dump({**table, "_meta": {"build_id": bid, "git": "abc1234"}}, open(prof / "r7" / "traffic_metrla.json", "w"))
+    monkeypatch.setattr(bench, "PROFILES_DIR", str(prof))
+    d, src = bench.traffic_profile("metrla", "bf16x3")
+    assert d is not None and src["status"] == "current" and src["file"].endswith("r7/traffic_metrla.json")
+    assert bench.pmc_traffic("metrla", "bf16x3", 207) == 30000000
+    st = bench.step_traffic("metrla", "bf16x3", 5.0)
+    assert st["step_fabric_gb"] == 15.0 and st["step_fabric_tbs"] == 3.0 and st["traffic_source"]["status"] == "current"
+    # a newer round's table from ANOTHER build: it is the newest, it is stale, nothing is reported (the older current one is not dug up)
+    json.dump({**table, "_meta": {"build_id": "0" * 16}}, open(prof / "r12" / "traffic_metrla.json", "w"))
+    d, src = bench.traffic_profile("metrla", "bf16x3")
+    assert d is None and src["status"].startswith("stale") and "r12" in src["file"]
+    assert bench.pmc_traffic("metrla", "bf16x3", 207) is None
+    st = bench.step_traffic("metrla", "bf16x3", 5.0)
+    assert "step_fabric_gb" not in st and st["traffic_source"]["status"].startswith("stale")
+    # a table without a build id (the round-5 format) is stale too; no table at all says so
+    json.dump(table, open(prof / "r12" / "traffic_metrla.json", "w"))
+    assert bench.traffic_profile("metrla", "bf16x3")[0] is None
+    assert bench.traffic_profile("pemsbay", "bf16x3")[1] == {"status": "absent"}
+    # tile tables: same rule
+    monkeypatch.setattr(bench, "TILE_DIR", str(tmp_path))
+    json.dump({"build_id": "0" * 16, "words": []}, open(bench.tile_cache_path("syn8192", 32, "bf16"), "w"))
+    assert not bench.tile_cache_current("syn8192", 32, "bf16") and not bench.import_tile_cache("syn8192", 32, "bf16")
+    json.dump({"build_id": bid, "words": []}, open(bench.tile_cache_path("syn8192", 32, "bf16"), "w"))
+    assert bench.tile_cache_current("syn8192", 32, "bf16") and bench.import_tile_cache("syn8192", 32, "bf16")
+
+
+def test_launch_histogram_abi():
+    from megacrn_amd import _lib
+    _lib.launch_histogram(reset=True)
+    assert _lib.launch_histogram() == {}          # (no GPU here: nothing launched since the reset)
+
+
 def test_workspace_sizing_and_validation():
     from megacrn_amd._lib import lib, Dims
     d = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 3, 0)

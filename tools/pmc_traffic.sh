@@ -67,6 +67,12 @@ for n, (k, f, w) in acc.items():
     res[n] = {"launches": k, "FETCH_SIZE_KiB": f / k, "WRITE_SIZE_KiB": w / k, "hbm_bytes_per_launch_corrected": b}
     total += b * k
 res["_step"] = {"fabric_bytes": total, "dispatches": len(fetch), "window": "between the last two k_clip_adam dispatches"}
+# which library these bytes belong to: bench.py reports them only when the library it loaded has the same build id
+import ctypes
+lib = ctypes.CDLL(os.environ["GRAFT_REPO_ROOT"] + "/megacrn_amd/libmegacrn_hip.so")
+lib.mcrn_build_id.restype = ctypes.c_char_p
+# (the GPU box has no .git: the caller passes the revision the snapshot was taken at, MCRN_GIT_REV=$(git rev-parse --short HEAD))
+res["_meta"] = {"build_id": lib.mcrn_build_id().decode(), "lib_version": int(lib.mcrn_version()), "git": os.environ.get("MCRN_GIT_REV")}
 json.dump(res, open(f"{root}/traffic_{tag}.json", "w"), indent=1, sort_keys=True)
 print(f"{tag}: one step = {len(fetch)} dispatches, {total / 1e9:.2f} GB through the fabric ports")
 for n, d in sorted(((n, d) for n, d in res.items() if n != "_step"), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:14]:
