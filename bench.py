@@ -32,6 +32,7 @@ CONFIGS = {
 SC_MEAN, SC_STD = 54.4, 19.5
 PEAK = {"f32": 157.3e12, "bf16x3": 2500e12, "bf16": 2500e12}
 HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: HBM3E 8 TB/s   # MI355X_MICROARCH.md dense MFMA peaks: fp32 / bf16
+MAX_CLOCK_MHZ = 2400.0                          # MI355X_MICROARCH.md: max clock, the clock the dense peaks are quoted at
 DEFAULT_PREC = {"metrla": "bf16x3", "pemsbay": "bf16x3", "expytky": "bf16", "syn8192": "bf16"}
 ROLE_NAMES = ["misc", "propagate", "weight_pool", "dgrad", "propagate_T", "adjacency_grad", "weight_grad", "propagate_inputs"]
 
@@ -333,9 +334,19 @@ def time_role(tr, batch, role, nrep):
     return ms.value, n.value, af.value, ef.value
 
 
+def held_clock():
+    """(MHz, stamped launches): shader clock inside the K loops of the bf16-resident products of the role profiled last (in-kernel
+    stamps, mcrn_prof_clock_mhz); (None, 0) for the roles that run other kernels."""
+    from megacrn_amd._lib import lib
+    mhz, nl = C.c_double(), C.c_longlong()
+    lib.mcrn_prof_clock_mhz(C.byref(mhz), C.byref(nl))
+    return (round(mhz.value, 1), nl.value) if nl.value > 0 and mhz.value > 0 else (None, 0)
+
+
 def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
     """`roofline` object of the forward K-hop propagation (the dominant kernel north_star names)."""
     ms, n, af, _ = time_role(tr, batch, 1, nrep)
+    mhz, n_stamped = held_clock()
     launch_s = ms * 1e-3 / n
     alg_flops = af / n
     alg_bytes = propagation_alg_bytes(cfg, B, dtype)
@@ -359,7 +370,11 @@ def roofline_of(tr, batch, cfg, config_name, B, dtype, nrep=5):
                     "PMC HBM bytes per launch (profiles/, tools/pmc_traffic.sh)"
                     + ("; bf16x3 issues 3 bf16 MFMAs per product: its matrix-core ceiling is 833 TF" if dtype == "bf16x3" else ""),
             "avg_launch_us": round(1e3 * ms / n, 3), "launches": n,
-            "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes}
+            "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
+            # the clock the chip HELD inside these launches' K loops (in-kernel stamps of workgroup 0: shader cycles / 100 MHz wall clock).
+            # `peak` above is the dense peak at 2.4 GHz; a power-limited part holds less under a dense-MFMA loop, and that is not the kernel's to win
+            **({"shader_clock_mhz": mhz, "clock_stamped_launches": n_stamped,
+                "frac_of_mfma_peak_at_held_clock": round(frac_mfma * MAX_CLOCK_MHZ / mhz, 5)} if mhz else {})}
 
 
 TILE_DIR = os.path.join(ROOT, "profiles", "tiles")

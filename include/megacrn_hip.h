@@ -240,6 +240,12 @@ int mcrn_set_gemm_cfg(int cfg);
 /* ablation bits for the GEMM main loop (results are WRONG when non-zero; tools/ablate.py only) */
 int mcrn_set_debug(int bits);
 int mcrn_prof_end(double* total_ms, long long* launches, double* alg_flops, double* exec_flops);
+/* Shader clock (MHz) the chip held inside the K loops of the bf16-resident products (gemm_bf16.h) profiled by the last
+ * mcrn_prof_begin / mcrn_prof_end pair: workgroup 0 of each such launch stamps the shader cycle counter and the 100 MHz wall clock at both
+ * ends of its K loop; *shader_mhz = sum of cycles / sum of wall time, *launches = stamped launches (0 and 0.0 when the role has no such
+ * product - the small-graph kernels).  MI355X clocks to its power budget: dense-MFMA loops run well below the 2.4 GHz at which the
+ * 2.5 PF bf16 peak is quoted, and bench.py reports the fraction of peak at the clock that was actually held beside the fraction of 2.5 PF. */
+int mcrn_prof_clock_mhz(double* shader_mhz, long long* launches);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

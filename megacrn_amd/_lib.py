@@ -23,7 +23,7 @@ EXPORTS = [
     "mcrn_agcn_workspace_bytes", "mcrn_agcn_forward", "mcrn_agcn_backward",
     "mcrn_cell_workspace_bytes", "mcrn_cell_forward", "mcrn_cell_backward",
     "mcrn_memory_workspace_bytes", "mcrn_memory_forward", "mcrn_memory_backward",
-    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_eval_metrics", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_autotune_export", "mcrn_autotune_import", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
+    "mcrn_flat_clip_adam", "mcrn_loss_fwd_bwd", "mcrn_eval_metrics", "mcrn_gemm_f32", "mcrn_prof_begin", "mcrn_prof_end", "mcrn_prof_clock_mhz", "mcrn_set_gemm_cfg", "mcrn_set_debug", "mcrn_model_autotune", "mcrn_autotune_entries", "mcrn_autotune_clear", "mcrn_autotune_export", "mcrn_autotune_import", "mcrn_set_precision", "mcrn_get_precision", "mcrn_set_side_stream",
 ]
 
 
@@ -132,6 +132,8 @@ def _load():
     lib.mcrn_prof_end.restype = i
     lib.mcrn_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]
+    lib.mcrn_prof_clock_mhz.restype = i
+    lib.mcrn_prof_clock_mhz.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     return lib
 
 

@@ -64,6 +64,11 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 #ifndef MCRN_BF16_ILV
 #define MCRN_BF16_ILV 3
 #endif
+#ifndef MCRN_BF16_G0C
+#define MCRN_BF16_G0C 1
+#endif
+// production probe (Bf16GemmP::clk, null outside the roofline leg): one thread of workgroup 0, two scalar clock reads and a 16-byte store
+#define MCRN_CLK_STAMP(P, i) do { if ((P).clk && blockIdx.x == 0 && threadIdx.x == 0) { (P).clk[2 * (i)] = clock64(); (P).clk[2 * (i) + 1] = wall_clock64(); } } while (0)
 #if MCRN_BF16_ABL & 8
 // bit 8: workgroup 0 records the shader-clock counter and the 100 MHz wall clock at both ends of the kernel (the clock the
 // chip really runs at under this load = d(clock64) / d(wall_clock64) x 100 MHz)
@@ -92,7 +97,7 @@ struct Bf16Tile {
     static constexpr int B_OFF = NOP * A_IMG;                           // stage layout: [A_hi | A_lo | B_hi | B_lo]
     static constexpr int STAGE = NOP * (A_IMG + B_IMG);                 // bytes
     static_assert(ASLOTS % 64 == 0 && BSLOTS % 64 == 0, "whole waves per pass");
-    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(BK == 16 || BK == 32 || BK == 64, "BK");     // (16: one MFMA step per K tile - the hi/lo form of the 256 x 256 tile, four stages in 128 KB)
 
     unsigned offA[AJ], offB[BJ];          // byte offsets of this thread's chunks from the tile's scalar base
     const uint16_t *baseA, *baseB;        // scalar: first element of the workgroup's rows / columns
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     }
 
+    MCRN_CLK_STAMP(p, 0);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nt) tl.issue(lds_base, s, wave);
@@ -558,6 +564,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
         }
         if (++rd == NSTAGE) rd = 0;
     }
+    MCRN_CLK_STAMP(p, 1);
     if (p.wide_cb && FN == 2 && (size_t)NW * WM * 128 <= (size_t)NSTAGE * T::STAGE) {   // (uniform: same barrier count for every wave)
         __syncthreads();                                         // every wave is done reading the operand stages
         if (bf16_epilogue_wide<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane, smem_bf16 + wave * (WM * 128), p.Cb, (int)p.cbm.lo)) return;
@@ -665,13 +672,25 @@ struct PpLoop {
         wait_landed(0);
         __syncthreads();
         int rd = 0, wr = NSTAGE - 1;                             // stage read next / stage the next DMA fills
+        // G0C (round 6, NSTAGE >= 3): group 0 also sends its share of a refill out BETWEEN the MFMAs of its compute phase (tile t + NSTAGE - 1
+        // into the stage tile t - 1 left: both groups have read it by phase 2t) instead of back to back behind the fragment reads of its
+        // load phase - that phase has to fit beside the partner's MFMA phase, and 4 - 8 DMA pieces at 100 - 185 cycles each were most of it.
+        // Two stages leave no room: a tile issued in phase 2t + 1 would be needed at the end of that same phase.
+        constexpr bool G0C = (MCRN_BF16_G0C != 0) && NSTAGE >= 3 && (MCRN_BF16_ILV & 2) != 0;
         if (grp == 0) {
             for (int t = 0; t < nt; ++t) {
+                const bool refill = !(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt;
                 load_frags(rd);                                  // phase 2t
-                if (!(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                // (issuing the refill BEFORE the fragment reads of this phase - it goes to another stage - measured 4 - 10 % slower:
+                //  profiles/r6/experiments.md section 4)
+                if (!G0C && refill) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                compute(std::false_type{}, false);               // phase 2t+1
+                if constexpr (G0C) {                             // phase 2t+1
+                    if (refill) tl.issue_begin(lds_base, wr, wave);
+                    compute(std::true_type{}, refill);
+                    if (refill) { tl.issue_end(); if (++wr == NSTAGE) wr = 0; }
+                } else compute(std::false_type{}, false);
                 if (t + 1 < nt) wait_landed(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
@@ -724,10 +743,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const Bf16GemmP p) {
     bf16_frag_offsets<L::FM, L::FN, BN, L::T::CH, L::T::RP, BTR>(wm * L::WM, wn * L::WN, lane, aoff, boff);
     f32x16_t acc[L::FM][L::FN];
     MCRN_CLK_PROBE(0);
+    MCRN_CLK_STAMP(p, 0);
     // (no accumulator preload here: this kernel sits at the 256-VGPR limit of two waves per SIMD, and the preload's address arithmetic
     //  pushed it into 556 bytes of scratch per lane - found in round 5 after the fact: launch_one_bf16_pp clears cin_pre)
     L::run(p, smem_bf16, lds_base, tid, wave, m_blk, n_blk, kt_beg, kt_end - kt_beg, aoff, boff, acc);
     MCRN_CLK_PROBE(1);
+    MCRN_CLK_STAMP(p, 1);
     if (p.wide_cb && L::FN == 2 && (size_t)8 * L::WM * 128 <= (size_t)NSTAGE * L::T::STAGE) {
         __syncthreads();                                         // both groups: every fragment read of the K loop has retired
         if (bf16_epilogue_wide<L::FM, L::FN>(p, acc, m_blk + wm * L::WM, n_blk + wn * L::WN, lane, smem_bf16 + wave * (L::WM * 128), p.Cb,
@@ -824,23 +845,27 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
 }
 #endif
 #if MCRN_BF16_PART != 1
-// hi/lo operand pairs (nterm == 3): the same tile shapes, every K tile 32 deep and FOUR images wide (A_hi, A_lo, B_hi, B_lo), so a stage
-// holds as many bytes as a 64-deep plain tile.  Slots whose plain form differs only in depth / stage count share a kernel (kCfgBf16X3Alias:
-// the tuner skips the duplicates); 320 x 256 does not fit the register file with two operand images.
+// hi/lo operand pairs (nterm == 3): the same tile shapes, every K tile FOUR images wide (A_hi, A_lo, B_hi, B_lo) and 16 or 32 deep, so a stage
+// holds as many bytes as a 32- / 64-deep plain tile.
 template <bool BTR, int ROLE>
 static inline hipError_t launch_cfg_bf16_x3(const Bf16GemmP& p, int cfg, int nsplit, hipStream_t st) {
     switch (cfg) {                                   //  BM   BN  waves  BK stages        LDS   workgroups / CU
         case 0: MCRN_CFG_ON(0) return launch_one_bf16<128, 128, 2, 2, 32, 2, BTR, ROLE, true>(p, nsplit, st);   //  64 KB   2
         case 1: MCRN_CFG_ON(1) return launch_one_bf16<256, 128, 4, 2, 32, 3, BTR, ROLE, true>(p, nsplit, st);   // 144 KB   1
         case 2: MCRN_CFG_ON(2) return launch_one_bf16<256, 256, 2, 4, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 128 KB   1
-        case 3: case 4: MCRN_CFG_ON(3) return launch_one_bf16_pp<256, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 128 KB   1   ping-pong
-        case 6: case 8: MCRN_CFG_ON(6) return launch_one_bf16_pp<192, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);   // 112 KB   1   ping-pong
+        // ping-pong, 16-deep K tiles (one MFMA step of three terms per tile): FOUR stages where the 32-deep form has two - a refill is issued
+        // 5 phases before it is read and group 0 sends its share between its MFMAs too (PpLoop G0C)
+        case 3: MCRN_CFG_ON(3) return launch_one_bf16_pp<256, 256, 16, 4, BTR, ROLE, true>(p, nsplit, st);      // 128 KB   1   ping-pong
+        case 4: MCRN_CFG_ON(4) return launch_one_bf16_pp<256, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);      // 128 KB   1   ping-pong, 32-deep phases
+        case 5: MCRN_CFG_ON(5) return launch_one_bf16_pp<320, 256, 16, 4, BTR, ROLE, true>(p, nsplit, st);      // 144 KB   1   ping-pong
+        case 6: MCRN_CFG_ON(6) return launch_one_bf16_pp<192, 256, 16, 4, BTR, ROLE, true>(p, nsplit, st);      // 112 KB   1   ping-pong
         case 7: MCRN_CFG_ON(7) return launch_one_bf16_pp<256, 128, 32, 3, BTR, ROLE, true>(p, nsplit, st);      // 144 KB   1   ping-pong
-        case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 32, 2, BTR, ROLE, true>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 8: MCRN_CFG_ON(8) return launch_one_bf16_pp<192, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);      // 112 KB   1   ping-pong, 32-deep phases
+        case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 16, 4, BTR, ROLE, true>(p, nsplit, st);      //  96 KB   1   ping-pong
         case 13: MCRN_CFG_ON(13) return launch_one_bf16<256, 128, 2, 2, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
         case 14: MCRN_CFG_ON(14) return launch_one_bf16<128, 256, 1, 4, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
         case 15: MCRN_CFG_ON(15) return launch_one_bf16<256, 192, 2, 2, 32, 2, BTR, ROLE, true>(p, nsplit, st);  // 112 KB   1
-        default: return hipErrorInvalidValue;                                              // 5 (320 x 256), retired slots
+        default: return hipErrorInvalidValue;                                              // retired slots
     }
 }
 hipError_t launch_gemm_bf16_hilo(const Bf16GemmP& p, bool btr, int cfg, int nsplit, int role, hipStream_t st) {

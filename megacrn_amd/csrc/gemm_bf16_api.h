@@ -30,7 +30,7 @@ struct Bf16GemmP {
     long long a_seg, b_seg;   // element offset between segments
     int nterm;                // 0 / 1: plain bf16 product.  3: hi/lo operand pairs - every K tile is FOUR images (A_hi, A_lo, B_hi, B_lo), fetched once,
     long long a_lo, b_lo;     //        multiplied as A_hi B_hi + A_hi B_lo + A_lo B_hi (the lo copies sit a_lo / b_lo elements behind the hi ones):
-                              //        the library's bf16x3 arithmetic on bf16-resident operands.  Both depths of K tile (32 / 64) count K tiles alike.
+                              //        the library's bf16x3 arithmetic on bf16-resident operands.  K tiles are 16 or 32 deep there (plain: 32 or 64).
     int M, N;                 // valid rows of A ; valid columns (NT: rows of B; NN: multiple of 8)
     float* C;                 // fp32 result (nullable when only the bf16 copy is wanted)
     const float* Cin;         // nullable
@@ -52,6 +52,10 @@ struct Bf16GemmP {
     // (hipExtLaunchKernelGGL), so that their elapsed time is the kernel's own begin -> end - what rocprofv3 reports - instead
     // of the span between two separately recorded event packets (~3 us longer per launch)
     void *ev0, *ev1;
+    // roofline leg only, else null: workgroup 0 stores {shader clock counter, 100 MHz wall clock} at both ends of its K loop (4 x u64).
+    // d(clock64) / d(wall_clock64) x 100 MHz = the clock the chip HOLDS under this kernel: MI355X clocks to its power budget, and a dense-MFMA
+    // loop on non-trivial data runs well below the 2.4 GHz the 2.5 PF peak is quoted at (profiles/r6/experiments.md section 2).
+    unsigned long long* clk;
 };
 
 // fills the derived fields (tps, split ranges) and launches tile configuration cfg (kCfgBf16) on stream st
@@ -66,14 +70,9 @@ static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 2
 // keep their meaning; the tuner skips them, a table naming one is refused, forcing one (MCRN_BF16_CFG) fails the launch.
 static const int CFG_BF16_SK0 = 10, CFG_BF16_SK1 = 13;
 static inline bool bf16_cfg_is_sk(int c) { return c >= CFG_BF16_SK0 && c < CFG_BF16_SK1; }
-// hi/lo operand pairs (nterm == 3): slots that share a kernel with a lower slot (same tile, the plain forms differ only in K depth / stages),
-// and the one tile that does not fit the register file with two operand images (320 x 256)
-static inline int bf16_cfg_x3_alias(int c) { return c == 4 ? 3 : (c == 8 ? 6 : c); }
-static inline bool bf16_cfg_ok(int c, bool x3) {
-    if (c < 0 || c >= NCFG_BF16 || bf16_cfg_is_sk(c)) return false;
-    return !x3 || c != 5;
-}
+// every live slot has a plain and a hi/lo (nterm == 3) form
+static inline bool bf16_cfg_ok(int c, bool x3) { (void)x3; return c >= 0 && c < NCFG_BF16 && !bf16_cfg_is_sk(c); }
 // ... and the slots the tuner times (duplicates skipped)
-static inline bool bf16_cfg_tuned(int c, bool x3) { return bf16_cfg_ok(c, x3) && (!x3 || bf16_cfg_x3_alias(c) == c); }
+static inline bool bf16_cfg_tuned(int c, bool x3) { return bf16_cfg_ok(c, x3); }
 
 }  // namespace mcrn

@@ -367,36 +367,21 @@ struct PropBlock {
 
 // forward, one workgroup per (32*CT columns, support s = blockIdx.y):
 //   plane[1+2s] = S_s plane[0] ;  plane[2+2s] = 2 S_s plane[1+2s] - plane[0]      (model/MegaCRN.py:20-25)
+// (body of one launch for the workgroup (bxi, s), S fragments already in ah / al: shared by prop2_fwd_kernel and by the persistent
+//  multi-cell prototype of tools/kbench/prop_chain_test.hip, which calls it once per cell between grid barriers)
 template <int NF, int CT>
-__global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
+__device__ __forceinline__ void prop2_fwd_units(const Prop2P& p, float* __restrict__ base, uint4* const img, const int bxi, const int s,
+                                                const uint4 (&ah)[PropBlock<NF, CT>::NAL], const uint4 (&al)[PropBlock<NF, CT>::NAL],
+                                                const uint4* __restrict__ sfw, const int ks0) {
     using PB = PropBlock<NF, CT>;
-    constexpr int KS = 2 * NF;
-    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
-    uint4* const img = prop2_img;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // 1-D grid of 16 * ceil(nblk / 8) workgroups: block b -> XCD b % 8, slot b / 8 -> (support = slot & 1, unit range (slot / 2) * 8 + XCD).
-    // The two supports of a unit range stage the SAME columns of plane 0: they share one XCD's L2 (round 5; with grid.y = support they
-    // landed on different XCDs whenever the range count is not a multiple of 8 - the METR-LA encoder: 68)
-    const int s = (int)((blockIdx.x >> 3) & 1);
-    const int bxi = (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
-    if (bxi >= p.nblk) return;                         // (padding of the last round; uniform over the workgroup)
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
-    const float* __restrict__ X0 = p.base;
-    float* __restrict__ X1 = p.base + (long long)(1 + 2 * s) * p.PS;
-    float* __restrict__ X2 = p.base + (long long)(2 + 2 * s) * p.PS;
+    const float* __restrict__ X0 = base;
+    float* __restrict__ X1 = base + (long long)(1 + 2 * s) * p.PS;
+    float* __restrict__ X2 = base + (long long)(2 + 2 * s) * p.PS;
     const int row0 = 32 * w + 4 * kq;
     const bool rows_in = 32 * w + 32 <= p.N;           // wave-uniform: every row of this wave exists
-
-    // S stays in registers while the workgroup walks its balanced range of column units: the grid is capped
-    // so that all workgroups are resident at once (no second round when #units is just above #CUs)
-    uint4 ah[PB::NAL], al[PB::NAL];
-    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
-    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;   // (kept live only where the fragments are streamed)
-    const int ks0 = PB::WIDE ? (int)((bxi * 7 + s * 3) % KS) : 0;
-    MCRN_TL(0, 0);
-    PB::load_a(sfw0, ah, al);
-    MCRN_TL(0, 1);
     const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
     const int u0 = (int)(((long long)bxi * nunits) / p.nblk), u1 = (int)(((long long)(bxi + 1) * nunits) / p.nblk);
     for (int unit = u0; unit < u1; ++unit) {
@@ -468,6 +453,31 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
         }
         MCRN_TL(0, 8);
     }   // unit loop
+}
+template <int NF, int CT>
+__global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
+    using PB = PropBlock<NF, CT>;
+    constexpr int KS = 2 * NF;
+    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
+    uint4* const img = prop2_img;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // 1-D grid of 16 * ceil(nblk / 8) workgroups: block b -> XCD b % 8, slot b / 8 -> (support = slot & 1, unit range (slot / 2) * 8 + XCD).
+    // The two supports of a unit range stage the SAME columns of plane 0: they share one XCD's L2 (round 5; with grid.y = support they
+    // landed on different XCDs whenever the range count is not a multiple of 8 - the METR-LA encoder: 68)
+    const int s = (int)((blockIdx.x >> 3) & 1);
+    const int bxi = (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
+    if (bxi >= p.nblk) return;                         // (padding of the last round; uniform over the workgroup)
+
+    // S stays in registers while the workgroup walks its balanced range of column units: the grid is capped
+    // so that all workgroups are resident at once (no second round when #units is just above #CUs)
+    uint4 ah[PB::NAL], al[PB::NAL];
+    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;   // (kept live only where the fragments are streamed)
+    const int ks0 = PB::WIDE ? (int)((bxi * 7 + s * 3) % KS) : 0;
+    MCRN_TL(0, 0);
+    PB::load_a(sfw0, ah, al);
+    MCRN_TL(0, 1);
+    prop2_fwd_units<NF, CT>(p, p.base, img, bxi, s, ah, al, sfw, ks0);
 #ifdef MCRN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) g_tl[0][blockIdx.x & 511][9] = wall_clock64();
@@ -482,30 +492,21 @@ __global__ __launch_bounds__(64 * NF) void prop2_fwd_kernel(const Prop2P p) {
 // The addends dP[1+2s] and dP[0] are loaded (clamped, unpredicated) straight into the accumulators before the MFMA
 // chain that adds to them, so no memory round trip sits between an MFMA phase and its stores.
 template <int NF, int CT>
-__global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
+__device__ __forceinline__ void prop2_bwd_units(const Prop2P& p, float* __restrict__ base, float* __restrict__ EX, uint4* const img,
+                                                const int bx, const int nbx, const int s,
+                                                const uint4 (&ah)[PropBlock<NF, CT>::NAL], const uint4 (&al)[PropBlock<NF, CT>::NAL],
+                                                const uint4* __restrict__ sfw, const int ks0) {
     using PB = PropBlock<NF, CT>;
-    constexpr int KS = 2 * NF;
-    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
-    uint4* const img = prop2_img;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = blockIdx.y;
     const int l31 = lane & 31, kq = lane >> 5;
     const int cperm = 4 * (l31 & 7) + (l31 >> 3);
-    float* __restrict__ D0 = p.base;
-    float* __restrict__ D1 = p.base + (long long)(1 + 2 * s) * p.PS;
-    const float* __restrict__ E2 = p.base + (long long)(2 + 2 * s) * p.PS;
-    float* __restrict__ EX = p.extra;
+    float* __restrict__ D0 = base;
+    float* __restrict__ D1 = base + (long long)(1 + 2 * s) * p.PS;
+    const float* __restrict__ E2 = base + (long long)(2 + 2 * s) * p.PS;
     const int row0 = 32 * w + 4 * kq;
     const bool rows_in = 32 * w + 32 <= p.N;
-    uint4 ah[PB::NAL], al[PB::NAL];
-    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
-    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;
-    const int ks0 = PB::WIDE ? (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS) : 0;
-    MCRN_TL(1, 0);
-    PB::load_a(sfw0, ah, al);
-    MCRN_TL(1, 1);
     const int nunits = p.nunits > 0 ? p.nunits : (p.ncols + 32 * CT - 1) / (32 * CT);
-    const int u0 = (int)(((long long)blockIdx.x * nunits) / gridDim.x), u1 = (int)(((long long)(blockIdx.x + 1) * nunits) / gridDim.x);
+    const int u0 = (int)(((long long)bx * nunits) / nbx), u1 = (int)(((long long)(bx + 1) * nunits) / nbx);
     for (int unit = u0; unit < u1; ++unit) {
         // (state columns only, see Prop2P: the first hop on the input channels - d1 += S^T e2, which the adjacency gradient reads -
         //  is a gathered single-hop launch on the helper stream: prop_mform.h, Prop1P::cstep)
@@ -586,6 +587,23 @@ __global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
         }
         MCRN_TL(1, 8);
     }   // unit loop
+}
+template <int NF, int CT>
+__global__ __launch_bounds__(64 * NF) void prop2_bwd_kernel(const Prop2P p) {
+    using PB = PropBlock<NF, CT>;
+    constexpr int KS = 2 * NF;
+    extern __shared__ __attribute__((aligned(16))) uint4 prop2_img[];   // PB::IMG uint4 (up to 132 KB at N = 352: dynamic)
+    uint4* const img = prop2_img;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = blockIdx.y;
+    uint4 ah[PB::NAL], al[PB::NAL];
+    const uint4* __restrict__ sfw0 = p.Sf[s] + (long long)w * KS * 2 * 64 + lane;
+    const uint4* __restrict__ sfw = PB::WIDE ? sfw0 : nullptr;
+    const int ks0 = PB::WIDE ? (int)((blockIdx.x * 7 + blockIdx.y * 3) % KS) : 0;
+    MCRN_TL(1, 0);
+    PB::load_a(sfw0, ah, al);
+    MCRN_TL(1, 1);
+    prop2_bwd_units<NF, CT>(p, p.base, p.extra, img, (int)blockIdx.x, (int)gridDim.x, s, ah, al, sfw, ks0);
 #ifdef MCRN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) g_tl[1][(blockIdx.y * gridDim.x + blockIdx.x) & 511][9] = wall_clock64();

@@ -363,27 +363,41 @@ def test_model_large_graph_vs_oracle(amd, N, cheb_k):
     assert max(worst.values()) < TOL, worst
 
 
-@pytest.mark.parametrize("N,B,H,D,T,why", [
-    (250, 320, 16, 8, 1, "8 row fragments (N > 224) with 96-column units: decoder B*Cp = 8960 columns = 140 64-column units > 128"),
-    (40, 5, 24, 8, 2, "streaming d-grad with 3 k-steps and its partial staging round (O = 48); O = 24 falls back to the tiled GEMM"),
-    (207, 3, 8, 8, 2, "streaming d-grad with a single k-step (O = 16); update O = 8 falls back"),
-    (40, 5, 40, 40, 2, "two-half streaming d-grad <5,2>: decoder gate O = 160 (encoder gate O = 80: <5,1>)"),
-    (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192"),
-    (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment"),
-    (45, 6, 32, 32, 2, "cheb_k=2: streaming weight pool with 2 propagated planes (wp_stream_kernel<2|4, 2, ..>), fp32 planes"),
+# `expect`: kernel FAMILIES (mcrn_launch_histogram) that must have launched in the bf16x3 session of the case - the kernel its `why`
+# names.  The plan picks kernels by shape; without this a plan edit can move a case off the path it was written for with every test
+# still green (round 5's verdict; the f32 session of the fixture runs the tiled GEMMs: checked for the x3r cases).
+@pytest.mark.parametrize("N,B,H,D,T,why,expect", [
+    (250, 320, 16, 8, 1, "8 row fragments (N > 224) with 96-column units: decoder B*Cp = 8960 columns = 140 64-column units > 128",
+     ("prop2_fwd", "prop2_bwd")),
+    (40, 5, 24, 8, 2, "streaming d-grad with 3 k-steps and its partial staging round (O = 48); O = 24 falls back to the tiled GEMM",
+     ("dgrad_stream", "tiled_x3:dgrad")),
+    (207, 3, 8, 8, 2, "streaming d-grad with a single k-step (O = 16); update O = 8 falls back", ("dgrad_stream", "tiled_x3:dgrad")),
+    (40, 5, 40, 40, 2, "two-half streaming d-grad <5,2>: decoder gate O = 160 (encoder gate O = 80: <5,1>)", ("dgrad_stream:two_half", "dgrad_stream")),
+    (40, 5, 48, 48, 2, "two-half streaming d-grad <6,2>: decoder gate O = 192", ("dgrad_stream:two_half",)),
+    (33, 4, 56, 56, 2, "two-half streaming d-grad <7,2>: decoder gate O = 224, ragged last row fragment", ("dgrad_stream:two_half",)),
+    (45, 6, 32, 32, 2, "cheb_k=2: streaming weight pool with 2 propagated planes (wp_stream_kernel<2|4, 2, ..>), fp32 planes",
+     ("wp_stream", "prop_small:fwd")),
     (400, 8, 32, 32, 3, "N > 352 in a bf16x3 session: the bf16-resident data flow with hi/lo operand pairs (x3r: stacked adjacency, hoisted forward and "
-                        "backward, one adjacency-gradient product per stack, three MFMAs per product) - the f32 session of the fixture runs the tiled path"),
-    (33, 4, 10, 6, 2, "H % 4 != 0: scalar GRU-backward kernels (k_cell_bwd_b / ca / c), scalar slab reduction (k_wunprep), tiled d-grad and weight pool"),
+                        "backward, one adjacency-gradient product per stack, three MFMAs per product) - the f32 session of the fixture runs the tiled path",
+     ("bf16_gemm_hilo:prop", "bf16_gemm_hilo:prop_in", "bf16_gemm_hilo:propT", "bf16_gemm_hilo:ds", "dgrad_stream:writes_hilo_operands")),
+    (400, 8, 32, 32, 2, "cheb_k=2 at N > 352 in a bf16x3 session: x3r with two stacked blocks [S1; S2], no T2 products (engine.hip lets cheb_k <= 3 onto x3r)",
+     ("bf16_gemm_hilo:prop", "bf16_gemm_hilo:prop_in", "bf16_gemm_hilo:propT", "bf16_gemm_hilo:ds")),
+    (384, 8, 32, 32, 2, "ycov_dim=3 at N > 352 in a bf16x3 session: x3r with a 4-channel decoder input (the (B*(od+yd)) % 8 branch of the plan; "
+                        "the hoisted input-channel product of the decoder is 4 channels wide)",
+     ("bf16_gemm_hilo:prop", "bf16_gemm_hilo:prop_in", "bf16_gemm_hilo:propT", "bf16_gemm_hilo:ds")),
+    (33, 4, 10, 6, 2, "H % 4 != 0: scalar GRU-backward kernels (k_cell_bwd_b / ca / c), scalar slab reduction (k_wunprep), tiled d-grad and weight pool",
+     ("k_cell_bwd:scalar", "k_wunprep:scalar", "tiled_x3:dgrad", "tiled_x3:wp")),
     (36, 3, 16, 8, 13, "T_in + T_out = 26 > 24: more BPTT cells than plane-set pairs - the rotating three-pair form with the caller's guard waits "
-                       "(up to 24 cells every cell owns its pair, ModelPlan::flat)"),
+                       "(up to 24 cells every cell owns its pair, ModelPlan::flat)", ("prop2_fwd", "prop2_bwd")),
     (48, 6, 32, 32, 3, "ycov_dim=5: decoder input of 6 channels (two column quads beside H_dec = 64): under MCRN_HOIST_FWD=2 the hoisted "
-                       "forward product and the state-only backward chain at an input width round 4's gathered first hop did not cover"),
+                       "forward product and the state-only backward chain at an input width round 4's gathered first hop did not cover", ("prop2_fwd",)),
 ])
-def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
+def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why, expect):
     """Shapes chosen to reach kernel variants the golden cases do not (see `why`): forward and every parameter
-    gradient of a train-mode step vs the float64 oracle."""
+    gradient of a train-mode step vs the float64 oracle - and the kernel family the case was written for did launch."""
+    import re
     M, cheb_k = 4, (2 if why.startswith("cheb_k=2") else 3)
-    yd = 5 if why.startswith("ycov_dim=5") else 1
+    yd = int(re.match(r"ycov_dim=(\d+)", why).group(1)) if why.startswith("ycov_dim=") else 1
     P = O.init_params(N, rnn_units=H, mem_num=M, mem_dim=D, cheb_k=cheb_k, seed=5, ycov_dim=yd)
     rng = np.random.default_rng(9)
     for k in P:
@@ -396,10 +410,18 @@ def test_model_kernel_variants_vs_oracle(amd, N, B, H, D, T, why):
     m = dict(N=N, T_out=T, H=H, num_layers=1, cheb_k=cheb_k, M=M, D=D, cl_decay=2000, ycov_dim=yd)
     model = build(amd, P, m).train()
     model._teacher_flags = lambda labels, bs: teacher
+    outs = model(dev(x), dev(ycov), dev(y), 0)           # (first call of the shape: workspace + tile autotune - its trial launches are counted too)
+    amd._lib.launch_histogram(reset=True)
     outs = model(dev(x), dev(ycov), dev(y), 0)
     wts = [rng.standard_normal(o.shape) for o in outs[:3]]
     sum((o * dev(w)).sum() for o, w in zip(outs[:3], wts)).backward()
     torch.cuda.synchronize()
+    hist = amd._lib.launch_histogram()
+    if amd.test_precision == amd._lib.BF16X3 and not os.environ.get("MCRN_HOIST_FWD"):
+        missing = [f for f in expect if hist.get(f, 0) == 0]
+        assert not missing, (why, "planned kernel families that did not launch:", missing, hist)
+    elif amd.test_precision == amd._lib.F32 and N > 352:
+        assert hist.get("tiled_f32:prop", 0) > 0 and not any(k.startswith("bf16_gemm") for k in hist), hist
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
     o64, cache = O.model_fwd(P64, x.astype(np.float64), ycov.astype(np.float64), y.astype(np.float64), teacher, cheb_k=cheb_k)
     for a, b in zip(outs[:3], o64[:3]):
@@ -767,8 +789,18 @@ def test_bf16_mode_train_step_vs_oracle(N, B, T, H, M, D, cheb_k):
     print("bf16 mode worst errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:6])
     assert max(errs.values()) < BF16_TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     # same inputs, same workspace: bit-identical
+    amd._lib.launch_histogram(reset=True)
     outs2 = model(dev(x), dev(ycov), dev(y), 0)
     assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+    # the forward pass ran on the bf16-resident product (one MFMA per product), not on a fallback: what the case's comment names
+    hist = amd._lib.launch_histogram()
+    assert hist.get("bf16_gemm:prop", 0) > 0 and not any(k.startswith(("bf16_gemm_hilo", "tiled_x3:prop", "prop2_fwd")) for k in hist), hist
+    hoisted = H % 32 == 0 and (H + D) % 32 == 0
+    assert (hist.get("bf16_gemm:prop_in", 0) > 0) == hoisted, (hoisted, hist)
+    # bf16-resident planes + the streaming weight pool on them: widths it takes, and (planes x decoder input channels) <= 16 (wp_stream_ok)
+    lite = hoisted and H in (32, 64, 128) and (H + D) in (32, 64, 128) and (2 * (cheb_k - 1) + 1) * (yd + 1) <= 16
+    assert (hist.get("wp_stream:bf16_planes", 0) > 0) == lite, (lite, hist)
+    assert (hist.get("hoisted_inputs:compact", 0) > 0) == (lite and yd + 1 <= 4), hist
 
 
 def _bf16_model(name, train):
@@ -942,6 +974,53 @@ def test_propagation_harness_matches_float64_reference():
         errs = [float(v) for v in re.findall(r"err ([0-9.e+-]+)", r.stdout)]
         assert len(errs) >= (2 if quick else 3), r.stdout[-1500:]
         assert max(errs) < 2e-5, (shape, max(errs), r.stdout[-1500:])
+
+
+_READY_EVENT_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, {root!r})
+import megacrn_amd
+from megacrn_amd.trainer import FlatTrainer
+torch.manual_seed(0); np.random.seed(0)
+N, B, T, H = 207, 16, 6, 64
+model = megacrn_amd.MegaCRN(num_nodes=N, input_dim=1, output_dim=1, horizon=T, rnn_units=H, mem_num=20, mem_dim=64).cuda().train()
+tr = FlatTrainer(model, lr=0.01, eps=1e-3, max_grad_norm=5, scaler_mean=54.4, scaler_std=19.5)
+g = torch.Generator(device="cpu").manual_seed(1)
+x, y = torch.randn(B, T, N, 1, generator=g).cuda(), torch.randn(B, T, N, 1, generator=g).cuda()
+ycov = torch.rand(B, T, N, 1, generator=g).cuda()
+h = hashlib.sha256()
+for step in range(40):                      # back to back, no synchronisation between steps: the helper stream stays loaded
+    tr.train_step(x, ycov, y)
+    if step % 8 == 7:
+        h.update(tr.flat_g.detach().cpu().numpy().tobytes())
+torch.cuda.synchronize()
+h.update(tr.flat_p.detach().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), float(tr.flat_g.abs().sum()))
+"""
+
+
+def test_attached_ready_event_orders_the_helper_stream():
+    """ADVICE (round 5): the helper stream's adjacency-gradient launch waits on an event that is ATTACHED to the dispatch of the fused
+    S^T chain (hipExtLaunchKernelGGL stop event) instead of recorded behind it.  If a runtime stopped treating that as a recorded event
+    for a cross-stream wait, the adjacency gradient would read d-grad planes too early and dWe1 / dWe2 would be intermittently wrong.
+    40 back-to-back train steps (METR-LA graph) in two fresh interpreters - attached (default) and MCRN_READY_EVENT=record, the
+    fallback switch - must produce bit-identical gradients and parameters."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for mode in ("attach", "record", "attach"):
+        e = dict(os.environ)
+        e.pop("MCRN_READY_EVENT", None)
+        if mode == "record":
+            e["MCRN_READY_EVENT"] = "record"
+        r = subprocess.run([sys.executable, "-c", _READY_EVENT_SCRIPT.format(root=root)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
+        assert float(line[2]) > 0
+        digests.setdefault(mode, set()).add(line[1])
+    assert len(digests["attach"]) == 1, "the attached form is not reproducible run to run"
+    assert digests["attach"] == digests["record"], digests
 
 
 # ------------------------------------------------------------------------------------------------
