@@ -451,7 +451,7 @@ static size_t g_flush_bytes = 0;
 static int g_force_cfg_bf16 = getenv("MCRN_BF16_CFG") ? atoi(getenv("MCRN_BF16_CFG")) : -1;
 static int bf16_cfg_prior(const Bf16GemmP& p, int nsplit) {
     // cost ~ (rounds over the CUs at this tile's residency) x (tile work) / (measured efficiency of the tile shape)
-    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8, 0, 0, 0, 0.85, 0.85, 0.85};
+    static const double eff[NCFG_BF16] = {0.65, 0.8, 0.85, 0.9, 1.0, 0.85, 0.8, 0.65, 0.9, 0.8, 0.8, 0.8, 0, 0.85, 0.85, 0.85};
     int best = 0; double bt = 1e300;
     for (int c = 0; c < NCFG_BF16; ++c) {
         if (!bf16_cfg_tuned(c, p.nterm == 3)) continue;
@@ -1651,7 +1651,10 @@ static void plan_model(const mcrn_dims_t* d, char* base, ModelPlan& P) {
     P.dPp[0] = P.dP; P.dQp[0] = P.dQ;
     {
         const int want = d->T_in + d->T_out;
-        P.flat = !P.bf16 && d->precision == MCRN_BF16X3 && want <= ModelPlan::MAXPAIR &&
+        // MCRN_FLAT_SETS=0 (read once): keep the rotating three-pair form - up to 8 GB less workspace on a smaller part, +1 % step time
+        // (one guard wait per BPTT cell; profiles/r5/experiments.md section 12).  Both forms are parity-tested (T_in + T_out = 26 case).
+        static const bool flat_off = getenv("MCRN_FLAT_SETS") && atoi(getenv("MCRN_FLAT_SETS")) == 0;
+        P.flat = !flat_off && !P.bf16 && d->precision == MCRN_BF16X3 && want <= ModelPlan::MAXPAIR &&
                  (double)want * 2.0 * (double)zmax * sizeof(float) <= 8e9;
         P.npair = P.flat ? want : ModelPlan::NPAIR;
     }

@@ -65,7 +65,10 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 #define MCRN_BF16_ILV 3
 #endif
 #ifndef MCRN_BF16_G0C
-#define MCRN_BF16_G0C 1
+#define MCRN_BF16_G0C 0
+#endif
+#ifndef MCRN_BF16_G1L
+#define MCRN_BF16_G1L 1
 #endif
 // production probe (Bf16GemmP::clk, null outside the roofline leg): one thread of workgroup 0, two scalar clock reads and a 16-byte store
 #define MCRN_CLK_STAMP(P, i) do { if ((P).clk && blockIdx.x == 0 && threadIdx.x == 0) { (P).clk[2 * (i)] = clock64(); (P).clk[2 * (i) + 1] = wall_clock64(); } } while (0)
@@ -672,11 +675,13 @@ struct PpLoop {
         wait_landed(0);
         __syncthreads();
         int rd = 0, wr = NSTAGE - 1;                             // stage read next / stage the next DMA fills
-        // G0C (round 6, NSTAGE >= 3): group 0 also sends its share of a refill out BETWEEN the MFMAs of its compute phase (tile t + NSTAGE - 1
-        // into the stage tile t - 1 left: both groups have read it by phase 2t) instead of back to back behind the fragment reads of its
-        // load phase - that phase has to fit beside the partner's MFMA phase, and 4 - 8 DMA pieces at 100 - 185 cycles each were most of it.
-        // Two stages leave no room: a tile issued in phase 2t + 1 would be needed at the end of that same phase.
+        // G0C (A/B build only, -DMCRN_BF16_G0C=1; NSTAGE >= 3): group 0 also sends its share of a refill out BETWEEN the MFMAs of its compute
+        // phase instead of behind the fragment reads of its load phase.  Measured 4 - 10 % SLOWER on every product (profiles/r6/experiments.md
+        // section 6): a DMA piece between MFMAs stalls the wave's in-order issue - the opposite move, G1L below, is the one that pays.
         constexpr bool G0C = (MCRN_BF16_G0C != 0) && NSTAGE >= 3 && (MCRN_BF16_ILV & 2) != 0;
+        // (measured per tile, profiles/r6/experiments.md section 6: 5 - 17 % fewer microseconds on every hi/lo tile and on the plain 256 x 256 /
+        //  320 x 256 / 192 x 256 tiles; the plain 256 x 128 x 32 tile - 8 MFMAs per phase, the shortest - is 4 - 7 % slower with it and keeps round 4's form)
+        constexpr bool G1L = (MCRN_BF16_G1L != 0) && NSTAGE >= 3 && !G0C && KS * NTM * FM * FN >= 16;
         if (grp == 0) {
             for (int t = 0; t < nt; ++t) {
                 const bool refill = !(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt;
@@ -694,6 +699,24 @@ struct PpLoop {
                 if (t + 1 < nt) wait_landed(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
+                if (++rd == NSTAGE) rd = 0;
+            }
+        } else if constexpr (G1L) {
+            // (round 6, NSTAGE >= 3) group 1 runs group 0's schedule one phase later: its share of tile t + NSTAGE - 1 goes out in its LOAD
+            // phase, into the stage tile t - 1 left (every read of that stage retired before the last barrier: no race, no extra wait).
+            // Between the MFMAs of the compute phase - round 4's form, kept where only two stages fit - every DMA piece holds the wave's
+            // in-order issue for 60 - 180 cycles at the address path: ~90 cycles of idle matrix pipe per piece, a fifth of the loop
+            // (profiles/r6/experiments.md section 6).  Here both compute phases are MFMA-only.
+            __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                load_frags(rd);                                  // phase 2t+1
+                if (!(MCRN_BF16_ABL & 1) && t + NSTAGE - 1 < nt) { tl.issue(lds_base, wr, wave); if (++wr == NSTAGE) wr = 0; }
+                if (t + 1 < nt) wait_landed(t + 1);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                compute(std::false_type{}, false);               // phase 2t+2
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < nt) __syncthreads();
                 if (++rd == NSTAGE) rd = 0;
             }
         } else {
@@ -834,7 +857,11 @@ static inline hipError_t launch_cfg_bf16(const Bf16GemmP& p, int cfg, int nsplit
         case 7: MCRN_CFG_ON(7) return launch_one_bf16_pp<256, 128, 32, 4, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong
         case 8: MCRN_CFG_ON(8) return launch_one_bf16_pp<192, 256, 64, 2, BTR, ROLE>(p, nsplit, st);      // 112 KB   1   ping-pong, 64-deep phases
         case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 64, 2, BTR, ROLE>(p, nsplit, st);      //  96 KB   1   ping-pong, 64-deep phases
-        case 10: case 11: case 12: return hipErrorInvalidValue;                           // retired slots (round 2's stream-K tiles, removed in round 5)
+        // (round 6) three-stage ping-pong tiles of 32K outputs: every DMA instruction in a load phase (G1L needs a third stage), 64-deep phases.
+        // 128 x 256: 64 x 64 wave tiles, 1.0 fragment reads per MFMA where 256 x 128 (128 x 32 wave tiles) has 1.25
+        case 10: MCRN_CFG_ON(10) return launch_one_bf16_pp<128, 256, 64, 3, BTR, ROLE>(p, nsplit, st);    // 144 KB   1   ping-pong
+        case 11: MCRN_CFG_ON(11) return launch_one_bf16_pp<256, 128, 64, 3, BTR, ROLE>(p, nsplit, st);    // 144 KB   1   ping-pong
+        case 12: return hipErrorInvalidValue;                                             // retired slot (round 2's stream-K tiles, removed in round 5)
         // FOUR waves (one per SIMD), 128 x 64 wave tiles: a 32K-output tile - the size that fills 256 CUs in one round on
         // the hoisted N = 1843 encoder product (7372 x 1024: 232 tiles) - read with 0.75 LDS fragment reads per MFMA, like
         // the 256 x 256 eight-wave tile (the eight-wave 256 x 128 forms have 64 x 64 or 128 x 32 wave tiles: 1.0 / 1.25)
@@ -862,6 +889,8 @@ static inline hipError_t launch_cfg_bf16_x3(const Bf16GemmP& p, int cfg, int nsp
         case 7: MCRN_CFG_ON(7) return launch_one_bf16_pp<256, 128, 32, 3, BTR, ROLE, true>(p, nsplit, st);      // 144 KB   1   ping-pong
         case 8: MCRN_CFG_ON(8) return launch_one_bf16_pp<192, 256, 32, 2, BTR, ROLE, true>(p, nsplit, st);      // 112 KB   1   ping-pong, 32-deep phases
         case 9: MCRN_CFG_ON(9) return launch_one_bf16_pp<256, 128, 16, 4, BTR, ROLE, true>(p, nsplit, st);      //  96 KB   1   ping-pong
+        case 10: MCRN_CFG_ON(10) return launch_one_bf16_pp<128, 256, 32, 3, BTR, ROLE, true>(p, nsplit, st);     // 144 KB   1   ping-pong
+        case 11: MCRN_CFG_ON(11) return launch_one_bf16_pp<128, 256, 16, 4, BTR, ROLE, true>(p, nsplit, st);     //  96 KB   1   ping-pong
         case 13: MCRN_CFG_ON(13) return launch_one_bf16<256, 128, 2, 2, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
         case 14: MCRN_CFG_ON(14) return launch_one_bf16<128, 256, 1, 4, 32, 3, BTR, ROLE, true>(p, nsplit, st);  // 144 KB   1
         case 15: MCRN_CFG_ON(15) return launch_one_bf16<256, 192, 2, 2, 32, 2, BTR, ROLE, true>(p, nsplit, st);  // 112 KB   1

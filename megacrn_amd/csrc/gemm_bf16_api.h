@@ -63,12 +63,12 @@ hipError_t launch_gemm_bf16(Bf16GemmP p, bool btr, int cfg, int nsplit, int role
 static const int NCFG_BF16 = 16;   // {BM, BN, workgroups per CU}: see launch_cfg_bf16
 static const int kCfgBf16[NCFG_BF16][3] = {{128, 128, 2}, {256, 128, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
                                            {320, 256, 1}, {192, 256, 1}, {256, 128, 1}, {192, 256, 1}, {256, 128, 1},
-                                           {256, 256, 1}, {256, 128, 1}, {192, 256, 1},
+                                           {128, 256, 1}, {256, 128, 1}, {192, 256, 1},
                                            {256, 128, 1}, {128, 256, 1}, {256, 192, 1}};
-// Slots CFG_BF16_SK0 .. CFG_BF16_SK1 - 1 are RETIRED (round 2's stream-K tiles: they only tied the best ping-pong configuration on the
-// N = 1843 products - profiles/r2/kbench_streamk.txt - and were removed in round 5).  The indices stay reserved so that tile tables
-// keep their meaning; the tuner skips them, a table naming one is refused, forcing one (MCRN_BF16_CFG) fails the launch.
-static const int CFG_BF16_SK0 = 10, CFG_BF16_SK1 = 13;
+// Slot 12 is RETIRED (the last of round 2's stream-K tiles; slots 10 and 11 were reused in round 6 for two three-stage ping-pong tiles - tile
+// tables are tied to a build by mcrn_build_id now, so an old table cannot name them by mistake).  The tuner skips it, a table naming it is
+// refused, forcing it (MCRN_BF16_CFG) fails the launch.
+static const int CFG_BF16_SK0 = 12, CFG_BF16_SK1 = 13;
 static inline bool bf16_cfg_is_sk(int c) { return c >= CFG_BF16_SK0 && c < CFG_BF16_SK1; }
 // every live slot has a plain and a hi/lo (nterm == 3) form
 static inline bool bf16_cfg_ok(int c, bool x3) { (void)x3; return c >= 0 && c < NCFG_BF16 && !bf16_cfg_is_sk(c); }

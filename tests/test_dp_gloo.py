@@ -185,8 +185,8 @@ def _tune_worker(rank, world, port, q):
                       LOCAL_RANK=str(rank))
     from megacrn_amd import dp, _lib
     dp.init_from_env("gloo")
-    # ranks "tuned" differently: {kind 0 (tiled GEMM key, 9 words), cfg} and {kind 1 (bf16 GEMM key, 6 words), cfg}
-    mine = [0, 9, 1, 207, 4352, 207, 2, 1, 0, 1, 0, 3 + rank, 1, 6, 1, 7372, 1152, 1843, 1, 1, 4 + rank]
+    # ranks "tuned" differently: {kind 0 (tiled GEMM key, 9 words), cfg} and {kind 1 (bf16 GEMM key, 7 words: ..., role, nterm), cfg}
+    mine = [0, 9, 1, 207, 4352, 207, 2, 1, 0, 1, 0, 3 + rank, 1, 7, 1, 7372, 1152, 1843, 1, 1, 1, 4 + rank]
     _lib.autotune_import(mine)
     assert _lib.autotune_export() == mine
     dp.share_autotune()
@@ -214,17 +214,20 @@ def test_ranks_adopt_rank0_tile_table_world2():
 
 def test_autotune_import_rejects_malformed_tables():
     from megacrn_amd import _lib
-    # (last: a retired bf16 tile slot, configurations 10..12 - round 2's stream-K tiles, removed in round 5)
-    for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 6] + [0] * 6 + [-1], [1, 6, 1, 7372, 1152, 1843, 1, 1, 11]):
+    # bf16 records: {1, 7 key words = btr, M, N, K, nsplit, role, nterm (a key word of its own since round 6), tile slot}
+    # (last two: the retired bf16 tile slot 12 - round 2's stream-K tiles - and a record in round 5's 6-word key format)
+    for bad in ([0, 9, 1], [2, 1, 0, 0], [0, 9] + [0] * 9 + [99], [1, 7] + [0] * 7 + [-1], [1, 7, 1, 7372, 1152, 1843, 1, 1, 1, 12],
+                [1, 6, 1, 7372, 1152, 1843, 1, 1, 4]):
         with pytest.raises(RuntimeError):
             _lib.autotune_import(bad)
     _lib.lib.mcrn_autotune_clear()
     _lib.autotune_import([])                      # (import merges into the table: nothing to merge, nothing there)
     assert _lib.autotune_export() == []
-    good = [1, 6, 1, 7372, 1152, 1843, 1, 1, 4]
+    good = [1, 7, 1, 7372, 1152, 1843, 1, 1, 1, 4]
     _lib.autotune_import(good)
-    _lib.autotune_import([1, 6, 1, 7372, 2048, 1843, 1, 1, 9])          # a second shape: merged, the first one stays
-    assert len(_lib.autotune_export()) == 2 * len(good)
+    _lib.autotune_import([1, 7, 1, 7372, 2048, 1843, 1, 1, 3, 9])       # a second shape (hi/lo pairs): merged, the first one stays
+    _lib.autotune_import([1, 7, 1, 7372, 1024, 1843, 1, 1, 1, 10])      # slots 10 / 11: ping-pong tiles since round 6 (retired stream-K slots reused)
+    assert len(_lib.autotune_export()) == 3 * len(good)
     _lib.lib.mcrn_autotune_clear()
 
 

@@ -85,6 +85,21 @@ def test_build_id_ties_measured_artefacts_to_the_library(tmp_path, monkeypatch):
     assert bench.tile_cache_current("syn8192", 32, "bf16") and bench.import_tile_cache("syn8192", 32, "bf16")
 
 
+def test_flat_plane_sets_have_an_opt_out():
+    """ADVICE (round 5): the per-cell gradient plane sets of the small graphs (ModelPlan::flat, up to 8 GB of workspace) can be switched
+    off for smaller parts: MCRN_FLAT_SETS=0, read at plan time in a fresh process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from megacrn_amd._lib import lib, Dims; "
+            "d = Dims(64, 207, 12, 12, 1, 1, 1, 64, 20, 64, 3, 1); print(lib.mcrn_model_workspace_bytes(C.byref(d)))" % ROOT)
+    sizes = {}
+    for v in ("1", "0"):
+        e = dict(os.environ)
+        e["MCRN_FLAT_SETS"] = v
+        sizes[v] = int(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split()[-1])
+    assert sizes["0"] < sizes["1"] - (1 << 30), sizes          # 21 pairs of plane sets less at METR-LA: > 1 GB
+
+
 def test_launch_histogram_abi():
     from megacrn_amd import _lib
     _lib.launch_histogram(reset=True)

@@ -17,5 +17,7 @@ done
 for c in metrla pemsbay expytky expytky_bf16x3; do cpy $src/traffic_${tag}_$c.json $dst/traffic_$c.json; done
 cpy $src/${tag}_expytky_bf16x3_steady.txt $dst/expytky_bf16x3_steady_kernels.txt
 for c in metrla expytky; do cpy $src/mfma_${tag}_$c.txt $dst/mfma_inmodel_$c.txt; done
+mkdir -p profiles/tiles; cpy $src/${tag}_tiles_syn8192_B32_bf16.json profiles/tiles/syn8192_B32_bf16.json
+[ -s $src/${tag}_default_command_kernel_stats.csv ] && cp $src/${tag}_default_command_kernel_stats.csv $dst/default_command_kernel_stats.csv
 [ -s $src/${tag}_metrla_noteacher_steady.txt ] && cp $src/${tag}_metrla_noteacher_steady.txt $dst/metrla_noteacher_steady_kernels.txt
 ls $dst
