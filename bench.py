@@ -617,7 +617,7 @@ def main():
             secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
         try:   # the same shape in the arithmetic that meets north_star's 1e-4 (3 MFMAs per product: its matrix-core ceiling is 833 TF)
-            secondary_parity = secondary_leg(device, steps=4, warmup=1, prec="bf16x3", regimes=False, nrep=1)
+            secondary_parity = secondary_leg(device, steps=8, warmup=2, prec="bf16x3", regimes=False, nrep=2)
         except Exception as e:
             secondary_parity = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
@@ -636,7 +636,7 @@ def main():
                                    f"(run by default only when that is free and at most half of the part; --with-syn forces it)"}
         else:
             try:
-                tertiary = secondary_leg(device, steps=2 if not args.with_syn else 3, warmup=1, name="syn8192", regimes=False, nrep=1,
+                tertiary = secondary_leg(device, steps=3, warmup=1, name="syn8192", regimes=False, nrep=1,
                                          tile_cache=True)
             except Exception as e:
                 tertiary = {"error": f"{type(e).__name__}: {e}"[:300]}

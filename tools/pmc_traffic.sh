@@ -25,9 +25,9 @@ def norm(n):
     m = re.match(r"^(gemm_f32_kernel|gemm_bf16x3_kernel)<.*, (true|false), (true|false), (\d+)>$", n)
     if m:
         return f"{m.group(1)}<*, {m.group(2)}, {m.group(3)}, {m.group(4)}>"
-    m = re.match(r"^gemm_bf16(?:_pp)?_kernel<.*, (true|false), (\d+)>$", n)
+    m = re.match(r"^gemm_bf16(?:_pp)?_kernel<.*, (true|false), (\d+)(?:, (true|false))?>$", n)      # <tile..., BTR, ROLE[, X3]>
     if m:
-        return f"gemm_bf16*<*, {m.group(1)}, {m.group(2)}>"
+        return f"gemm_bf16*<*, {m.group(1)}, {m.group(2)}>" + (" hi/lo" if m.group(3) == "true" else "")
     return n
 
 
@@ -75,7 +75,7 @@ lib.mcrn_build_id.restype = ctypes.c_char_p
 res["_meta"] = {"build_id": lib.mcrn_build_id().decode(), "lib_version": int(lib.mcrn_version()), "git": os.environ.get("MCRN_GIT_REV")}
 json.dump(res, open(f"{root}/traffic_{tag}.json", "w"), indent=1, sort_keys=True)
 print(f"{tag}: one step = {len(fetch)} dispatches, {total / 1e9:.2f} GB through the fabric ports")
-for n, d in sorted(((n, d) for n, d in res.items() if n != "_step"), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:14]:
+for n, d in sorted(((n, d) for n, d in res.items() if n[:1] != "_"), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:14]:
     print(f"{n[:60]:60s} n={d['launches']:4d} fetch={d['FETCH_SIZE_KiB']/1024:8.2f}MiB write={d['WRITE_SIZE_KiB']/1024:8.2f}MiB  step share {d['hbm_bytes_per_launch_corrected'] * d['launches'] / total:5.1%}")
 PY
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmct_${tag}_[12]
