@@ -976,6 +976,34 @@ def test_propagation_harness_matches_float64_reference():
         assert max(errs) < 2e-5, (shape, max(errs), r.stdout[-1500:])
 
 
+def test_bf16_gemm_harness_every_tile_slot_plain_and_hilo():
+    """tools/kbench/bf16_gemm_test: EVERY tile slot of gemm_bf16.h in both forms - plain (one MFMA per product) and hi/lo operand pairs (a K tile
+    of four images, three MFMA blocks) - on ragged shapes (edge tiles in M and N, K tails inside a segment, several segments, split-K, the
+    bf16 copy of the result), each against the float64 product of the same operands.  The model-level parity cases reach the slots the tuner
+    picks; this reaches all of them.  Skipped when the harness binary is not in the tree (it takes five minutes to compile:
+    `make -C megacrn_amd/csrc kbench-all`)."""
+    import re
+    import subprocess
+    kb = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kbench")
+    exe = os.path.join(kb, "bf16_gemm_test")
+    if not os.path.exists(exe):
+        pytest.skip("tools/kbench/bf16_gemm_test not built")
+    shapes = ("333 136 77 2 nn {c} 1 2 1", "300 200 88 3 nt {c} 2 2", "700 333 200 2 nt {c} 3 2", "1000 520 40 1 nn {c} 1 2 1")
+    for x3 in (False, True):
+        for c in [c for c in range(16) if c != 12]:                  # 12: the retired slot
+            for sh in shapes:
+                e = dict(os.environ)
+                e.pop("X3", None)
+                if x3:
+                    e["X3"] = "1"
+                r = subprocess.run([exe] + sh.format(c=c).split(), env=e, cwd=kb, capture_output=True, text=True, timeout=120)
+                assert r.returncode == 0 and "  OK " in r.stdout, (x3, c, sh, r.stdout[-600:] + r.stderr[-300:])
+                rel = float(re.search(r"rel ([0-9.e+-]+)\)", r.stdout).group(1))
+                assert rel < (1e-5 if x3 else 2e-6), (x3, c, sh, rel)       # hi/lo: ~4e-6 of fp32 operands; plain: bf16 operands are exact inputs
+    r = subprocess.run([exe, "333", "136", "77", "2", "nn", "12", "1", "2"], cwd=kb, capture_output=True, text=True, timeout=120)
+    assert "launch failed" in r.stdout                               # the retired slot fails loudly
+
+
 _READY_EVENT_SCRIPT = r"""
 import sys, hashlib, numpy as np, torch
 sys.path.insert(0, {root!r})
