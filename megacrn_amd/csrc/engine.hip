@@ -687,8 +687,8 @@ static int prop_bwd_bf16(const Shp& s, const Sup& u, float* dP, const uint16_t* 
     p.B = dPb; p.ldb = s.ldp; p.N = (int)s.ld;
     p.nseg = u.nb; p.seg_len = s.N; p.a_seg = u.Kp; p.b_seg = s.PSb;
     p.C = dP; p.Cin = dP; p.beta = 1.f; p.cm = rm_plain(s.ld);
-    p.cin_pre = 1;                               // the K loop starts FROM plane 0: no read-modify-write epilogue (gemm_bf16.h, bf16_acc_preload;
-                                                 // 58.0 -> 55.8 us per launch, EXPY-TKY step +0.7 %: profiles/r5/experiments.md section 2)
+    p.cin_pre = 1;                               // asks for the accumulator preload; honoured only by -DMCRN_BF16_PRELOAD=1 builds (round 6: the shipped
+                                                 // kernels add plane 0 in the epilogue again - the preload's SGPRs cost more than its loads saved, gemm_bf16.h)
     if (hoisted) { p.ldb = s.ldh; p.N = (int)s.ldh; p.b_seg = s.PSbh; p.cn_inner = s.H; p.cn_hi = s.Cp; }
     x3_terms(p, u.lo_STstk, s.lo_dPb);
     int nsplit = 1;

@@ -64,6 +64,13 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 #ifndef MCRN_BF16_ILV
 #define MCRN_BF16_ILV 3
 #endif
+// Accumulator preload (round 5: the split-0 workgroups of the transposed propagation start their K loop FROM the addend instead of adding it in
+// the epilogue).  OFF since round 6 (A/B build: -DMCRN_BF16_PRELOAD=1 compiles it into the ROLE 4 kernels): its address arithmetic took the ring
+// kernel from 84 to 104 SGPRs and cost every instantiation 6 - 7 % per launch, taken or not - more than it saved where it was taken
+// (transposed product at N = 1843: 55.1 - 56.1 us with it in the ROLE 4 kernels only, 52.9 - 53.2 us without; profiles/r6/experiments.md section 8).
+#ifndef MCRN_BF16_PRELOAD
+#define MCRN_BF16_PRELOAD 0
+#endif
 #ifndef MCRN_BF16_G0C
 #define MCRN_BF16_G0C 0
 #endif
@@ -448,8 +455,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const Bf16Gem
     bf16_frag_offsets<FM, FN, BN, T::CH, T::RP, BTR>(wm * WM, wn * WN, lane, aoff, boff);
 
     f32x16_t acc[FM][FN];
-    if (p.cin_pre && split == 0) bf16_acc_preload<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane);      // workgroup-uniform
-    else {
+    // (see MCRN_BF16_PRELOAD: round 5 had this branch in EVERY instantiation - the "encoder tile regression" of the round-5 review, bisected in round 6)
+    bool preloaded = false;
+    if constexpr (ROLE == 4 && MCRN_BF16_PRELOAD != 0) {
+        if (p.cin_pre && split == 0) { bf16_acc_preload<FM, FN>(p, acc, m_blk + wm * WM, n_blk + wn * WN, lane); preloaded = true; }   // workgroup-uniform
+    }
+    if (!preloaded) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -791,6 +802,7 @@ static inline void bf16_split_plan(Bf16GemmP& p, int BK, int nsplit) {
 }
 template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool BTR, int ROLE, bool X3 = false>
 static inline hipError_t launch_one_bf16(Bf16GemmP p, int nsplit, hipStream_t st) {
+    if (ROLE != 4 || MCRN_BF16_PRELOAD == 0) p.cin_pre = 0;   // (only the ROLE 4 instantiations carry the preload: everybody else adds Cin in the epilogue)
     bf16_split_plan(p, BK, nsplit);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * (BK / 8) * 16 * (X3 ? 2 : 1);
