@@ -43,12 +43,19 @@ static __global__ void k_wfrag_build(const float* __restrict__ W, long long ld, 
 // KH = 2 (128 < O <= 256, the decoder gate of the H = 64 configurations): the K extent is walked in two halves of KS
 // k-steps; the wave keeps BOTH halves of its dY rows resident (16 KS VGPRs), a column fragment is staged and multiplied
 // half by half into the same accumulators and stored after the second.
-template <int KS, int KH = 1>
+// OUT (round 6): which output forms the instantiation carries.  0 = fp32 gradient planes only (the small graphs, the tiled large-graph path),
+// 1 = + bf16 gradient planes, 2 = + the hoisted backward's packed state channels / stack-wide input operand (hi and hi/lo).  Until round 6 every
+// instantiation carried all three: the fp32-only kernels of METR-LA paid for the other two with 65 VGPRs and 30 SGPRs (<8, 1>: 195 -> 130 VGPRs, a third
+// wave per SIMD; <8, 2>: 256 + 12 B of scratch -> 194) - at the register limit a path that is never taken is not free (profiles/r6/experiments.md 8, 9).
+template <int KS, int KH = 1, int OUT = 0>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) void dgrad_stream_kernel(const DgradP p) {   // <= 3 waves per SIMD: keeps the compiler from spilling the staging registers to reach a higher occupancy
     constexpr int FRAG = KS * 2 * 64;                                 // uint4 per staged piece: one column fragment, one K half (hi and lo)
     constexpr int NLD = (FRAG + 255) / 256;                           // uint4 per thread to stage one piece
     constexpr int OH = 16 * KS, O = OH * KH;                          // columns of dY per half / in all
-    constexpr int AROW = OH + 4;                                      // padded row (floats) of the A bounce buffer
+    // the A bounce buffer takes the wave's 32 rows in column CHUNKS of CW <= 64 (round 6): at O = 128 the whole-row buffer was 68 KB per workgroup
+    // and held the kernel at two workgroups per CU whatever its registers; in 64-column chunks it is 35 KB (the two B stages: 32 KB)
+    constexpr int NCH = (OH > 64 && KS % 2 == 0) ? 2 : 1, CW = OH / NCH;
+    constexpr int AROW = CW + 4;                                      // padded row (floats) of the A bounce buffer
     constexpr int ABYTES = 4 * 32 * AROW * 4, BBYTES = 2 * FRAG * 16;
     // one LDS region: first the four waves' A bounce buffers, then (after a barrier) the two B stages
     __shared__ __attribute__((aligned(16))) unsigned char smem_[ABYTES > BBYTES ? ABYTES : BBYTES];
@@ -83,24 +90,25 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         float* __restrict__ sa = reinterpret_cast<float*>(smem_) + wave * 32 * AROW;
         const long long lim = p.R * O;                                // floats in dY
 #pragma unroll
-        for (int h = 0; h < KH; ++h) {
-            {
+        for (int h = 0; h < KH; ++h)
 #pragma unroll
-            for (int i = 0; i < OH / 8; ++i) {                        // 32*OH/4 float4 over 64 lanes
-                const int e = lane + 64 * i;                          // float4 index inside the (32 x OH) block
-                const int row = (4 * e) / OH, k = (4 * e) % OH;
-                long long src = (rf * 32 + row) * O + h * OH + k;     // (KH == 1: the 32 rows are one contiguous block)
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int i = 0; i < CW / 8; ++i) {                        // 32*CW/4 float4 over 64 lanes
+                const int e = lane + 64 * i;                          // float4 index inside the (32 x CW) block
+                const int row = (4 * e) / CW, k = (4 * e) % CW;
+                long long src = (rf * 32 + row) * O + h * OH + ch * CW + k;   // (a row's chunk: CW contiguous floats)
                 if (src + 4 > lim) src = lim - 4;                     // rows beyond R: any valid address, never stored
                 if (src < 0) src = 0;
                 const float4 x = *reinterpret_cast<const float4*>(p.dY + src);
                 *reinterpret_cast<float4*>(sa + row * AROW + k) = x;
             }
-            }
-            // same wave wrote and reads (and overwrites for the next half): LDS operations of a wave complete in order
+            // same wave wrote and reads (and overwrites for the next chunk / half): LDS operations of a wave complete in order
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4 x = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq);
-                const float4 y = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * ks + 8 * kq + 4);
+            for (int kc = 0; kc < CW / 16; ++kc) {
+                const int ks = ch * (CW / 16) + kc;
+                const float4 x = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * kc + 8 * kq);
+                const float4 y = *reinterpret_cast<const float4*>(sa + l31 * AROW + 16 * kc + 8 * kq + 4);
                 const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
                 split8(v, ah[h * KS + ks], al[h * KS + ks]);
             }
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
             const int g = n / p.Cp;
             int cp = p.Cp;
             asm volatile("" : "+s"(cp));                               // row offsets stay scalar multiples, not 16 live VGPR pairs
-            if (p.dPb && g > 0 && p.H > 0) {                           // hoisted backward: packed state channels / stack-wide input operand
+            if (OUT == 2 && p.dPb && g > 0 && p.H > 0) {               // hoisted backward: packed state channels / stack-wide input operand
                 const int cc = n - g * p.Cp;
                 if (cc < p.H) {
                     unsigned short* __restrict__ c = p.dPb + (long long)(g - 1) * p.PSb + cc + r0 * p.H;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 3))) 
                         if (++bb == (unsigned)p.B) { bb = 0; ++nn; }
                     }
                 }
-            } else if (p.dPb && g > 0) {                               // bf16 gradient plane (same row / column indexing)
+            } else if (OUT == 1 && p.dPb && g > 0) {                   // bf16 gradient plane (same row / column indexing)
                 unsigned short* __restrict__ c = p.dPb + (long long)(g - 1) * p.PSb + (n - g * p.Cp) + r0 * p.Cp;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
@@ -243,21 +251,30 @@ static inline hipError_t launch_dgrad_stream(DgradP p, hipStream_t st) {
     p.cf_per_part = (int)((p.ncf + parts - 1) / parts);
     p.parts = (p.ncf + p.cf_per_part - 1) / p.cf_per_part;
     dim3 grid((unsigned)(((nrg + 7) / 8) * 8 * p.parts));             // 8 row groups (one per XCD) per round of `parts` workgroups each
+    // output form of this launch (see OUT): decided by the fields the caller filled in
+    const int out = p.dPb ? (p.H > 0 ? 2 : 1) : 0;
+#define MCRN_DG_LAUNCH(KS_, KH_)                                                                                            \
+    do {                                                                                                                    \
+        if (out == 2) hipLaunchKernelGGL((dgrad_stream_kernel<KS_, KH_, 2>), grid, dim3(256), 0, st, p);                    \
+        else if (out == 1) hipLaunchKernelGGL((dgrad_stream_kernel<KS_, KH_, 1>), grid, dim3(256), 0, st, p);               \
+        else hipLaunchKernelGGL((dgrad_stream_kernel<KS_, KH_, 0>), grid, dim3(256), 0, st, p);                             \
+    } while (0)
     switch (p.O / 16) {
-        case 1: hipLaunchKernelGGL(dgrad_stream_kernel<1>, grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(dgrad_stream_kernel<2>, grid, dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(dgrad_stream_kernel<3>, grid, dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(dgrad_stream_kernel<4>, grid, dim3(256), 0, st, p); break;
-        case 5: hipLaunchKernelGGL(dgrad_stream_kernel<5>, grid, dim3(256), 0, st, p); break;
-        case 6: hipLaunchKernelGGL(dgrad_stream_kernel<6>, grid, dim3(256), 0, st, p); break;
-        case 7: hipLaunchKernelGGL(dgrad_stream_kernel<7>, grid, dim3(256), 0, st, p); break;
-        case 8: hipLaunchKernelGGL(dgrad_stream_kernel<8>, grid, dim3(256), 0, st, p); break;
-        case 10: hipLaunchKernelGGL((dgrad_stream_kernel<5, 2>), grid, dim3(256), 0, st, p); break;
-        case 12: hipLaunchKernelGGL((dgrad_stream_kernel<6, 2>), grid, dim3(256), 0, st, p); break;
-        case 14: hipLaunchKernelGGL((dgrad_stream_kernel<7, 2>), grid, dim3(256), 0, st, p); break;
-        case 16: hipLaunchKernelGGL((dgrad_stream_kernel<8, 2>), grid, dim3(256), 0, st, p); break;
+        case 1: MCRN_DG_LAUNCH(1, 1); break;
+        case 2: MCRN_DG_LAUNCH(2, 1); break;
+        case 3: MCRN_DG_LAUNCH(3, 1); break;
+        case 4: MCRN_DG_LAUNCH(4, 1); break;
+        case 5: MCRN_DG_LAUNCH(5, 1); break;
+        case 6: MCRN_DG_LAUNCH(6, 1); break;
+        case 7: MCRN_DG_LAUNCH(7, 1); break;
+        case 8: MCRN_DG_LAUNCH(8, 1); break;
+        case 10: MCRN_DG_LAUNCH(5, 2); break;
+        case 12: MCRN_DG_LAUNCH(6, 2); break;
+        case 14: MCRN_DG_LAUNCH(7, 2); break;
+        case 16: MCRN_DG_LAUNCH(8, 2); break;
         default: return hipErrorInvalidValue;
     }
+#undef MCRN_DG_LAUNCH
     return hipGetLastError();
 }
 

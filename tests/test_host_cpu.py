@@ -313,8 +313,9 @@ def test_shipped_kernels_do_not_spill():
     sizes = mod.scratch_sizes(so)
     assert len(sizes) > 200 and any(k.startswith("gemm_bf16_pp_kernel<") for k in sizes)      # we really looked at the kernels
     # known, measured spills of the widest fused two-hop variants (K = 3 planes of a 7- or 8-fragment adjacency row band) and one d-grad form
-    allowed = {"prop2_fwd_kernel<8, 3>": 160, "prop2_bwd_kernel<8, 3>": 72, "prop2_fwd_kernel<7, 3>": 64, "prop2_bwd_kernel<7, 3>": 24,
-               "dgrad_stream_kernel<8, 2>": 20}
+    # (round 6: the bodies of the fused two-hop kernels as device functions and the d-grad's output forms as a template parameter removed the
+    #  other three; what is left is the widest propagation variant and the hoisted-backward form of the widest d-grad)
+    allowed = {"prop2_fwd_kernel<8, 3>": 8, "dgrad_stream_kernel<8, 2, 2>": 12}
     bad = {k: v for k, v in sizes.items() if v > allowed.get(k, 0)}
     assert not bad, f"kernels with new register spills (bytes per lane): {bad}"
 
