@@ -585,8 +585,8 @@ static int prop_fwd_bf16(const Shp& s, const Sup& u, float* Z, uint16_t* x0b, ui
     if (s.hoist) {
         // only the state channels change from step to step: B = their packed bf16 copy (N x B*H), the result lands in the
         // h-channel block of every (node, sample) row of planes 1 .. nb; the input-channel blocks were filled by hoist_inputs
-        PackX xs_; xs_.lo = s.lo_x0b;
-        CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st, xs_));
+        // (packed: the weight-pool epilogue that produced the state already wrote the operand, hi and lo image - round 6, x3r)
+        if (!packed) { PackX xs_; xs_.lo = s.lo_x0b; CKI(pack_cols_bf16(Z, 0, s, 0, s.H, 1, (int)s.ldh, x0b, st, xs_)); }
         p.B = x0b; p.ldb = s.ldh; p.N = (int)s.ldh;
         p.cn_inner = s.H; p.cn_hi = s.Cp;
         x3_terms(p, u.lo_Sstk, s.lo_x0b);
@@ -1235,9 +1235,10 @@ struct CellW { const float *Wf_g, *Wd_g, *bg, *Wf_u, *Wd_u, *bu; const uint4 *if
 // streaming weight pool on bf16-resident planes (wp_stream.h) with the library's profiling hooks
 static int wp_stream(const Shp& s, const Sup& u, const float* Z, const uint16_t* Pb, const uint4* img, const float* bias, int epi,
                      float* out, float* out2, long long out2_ld, uint16_t* out2b, const float* hsrc, long long hsrc_ld,
-                     const float* zr, hipStream_t st, const float* xc = nullptr) {
+                     const float* zr, hipStream_t st, const float* xc = nullptr, long long out2b_lo = 0) {
     WpP q;
     memset(&q, 0, sizeof q);
+    q.out2b_lo = out2b ? out2b_lo : 0;
     q.Xc = xc; q.xc_plane = s.R * 4;
     q.Z = Z; q.Pb = Pb; q.PS = s.PS; q.PSh = s.R * s.H; q.R = s.R; q.Cp = s.Cp; q.H = s.H; q.d = s.d; q.nbp = u.nb;
     q.O = epi == WP_GATE ? 2 * s.H : s.H; q.Wimg = img; q.bias = bias; q.epi = epi;
@@ -1265,10 +1266,13 @@ static int cell_fwd_core(const Shp& s, const Sup& u, float* Z, float* Y, float* 
     }
     if (w.wp_g && w.wp_u && g_precision == MCRN_BF16X3 && aligned16(Z) && aligned16(Y)) {
         // streaming weight pool on fp32 planes (bf16x3 arithmetic: the 1e-4 parity mode of the small graphs)
-        CKI(prop_fwd(s, u, Z, st, x0b, x0c));
-        CKI(wp_stream(s, u, Z, nullptr, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, nullptr, nullptr, 0, nullptr, st));
-        CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PSb : nullptr, x0c ? x0c + s.PSb : nullptr));
-        CKI(wp_stream(s, u, Y, nullptr, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, nullptr, Z, s.Cp, zr, st));
+        // x3r (N > 352, hi/lo operand pairs): the GRU epilogues also emit the packed hi/lo operand of the NEXT propagation product
+        // (gate: z*h -> the update call; update: h' -> the next cell's gate call), so only the first cell of a stack runs the pack pass
+        const bool emit = g_x3r && g_prop_bf16 && s.hoist && x0b != nullptr;
+        CKI(prop_fwd(s, u, Z, st, x0b, x0c, nullptr, emit && packed));
+        CKI(wp_stream(s, u, Z, nullptr, w.wp_g, w.bg, WP_GATE, zr, Y, s.Cp, emit ? x0b + s.PSb : nullptr, nullptr, 0, nullptr, st, nullptr, s.lo_x0b));
+        CKI(prop_fwd(s, u, Y, st, x0b ? x0b + s.PSb : nullptr, x0c ? x0c + s.PSb : nullptr, nullptr, emit));
+        CKI(wp_stream(s, u, Y, nullptr, w.wp_u, w.bu, WP_UPDATE, hc, hnext, hnext_ld, emit ? x0b_next : nullptr, Z, s.Cp, zr, st, nullptr, s.lo_x0b));
         return 0;
     }
     CKI(prop_fwd(s, u, Z, st, x0b, x0c));
@@ -2000,14 +2004,17 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
     const int Os[4] = {2 * H, H, 2 * Hd, Hd};
     for (int i = 0; i < 4; ++i) CKI(wprep(Wsrc[i], P.Wf[i], P.Wd[i], i < 2 ? se : sd, Os[i], ps, P.imgf[i], P.imgd[i]));
     const bool lite = P.bf16 && P.Pb_e != nullptr;
-    if (lite && P.Kp > N) {
+    if ((lite || P.x3r) && P.Kp > N) {
         // the propagation operands [Kp][B*H] that the weight-pool epilogues emit cover the N data rows only: their pad
-        // rows must be finite (gemm_bf16.h contract: they meet the zero K-padding of the stacked adjacency)
+        // rows must be finite (gemm_bf16.h contract: they meet the zero K-padding of the stacked adjacency); x3r: the lo images too
         for (int e_ = 0; e_ < 2; ++e_) {
             const Shp& s_ = e_ ? sd : se;
             const long long np_ = (long long)2 * (e_ ? To : Ti), per = (long long)(s_.Kp - N) * (s_.ldh / 8);
             LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, ps, reinterpret_cast<uint4*>(e_ ? P.x0b_d : P.x0b_e),
                    s_.PSb / 8, N, s_.Kp, (int)(s_.ldh / 8), np_);
+            if (s_.lo_x0b > 0)
+                LAUNCH(k_zero_pad_rows, dim3(cdiv(per * np_, 256)), dim3(256), 0, ps, reinterpret_cast<uint4*>((e_ ? P.x0b_d : P.x0b_e) + s_.lo_x0b),
+                       s_.PSb / 8, N, s_.Kp, (int)(s_.ldh / 8), np_);
         }
     }
     const bool wps = P.wpimg[0] != nullptr;
@@ -2069,7 +2076,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                           we, P.Zenc + (t + 1) * se.ZT, se.Cp, st, P.bf16 ? P.x0b_e + (long long)2 * t * se.PSb : nullptr,
                           P.bf16 ? P.x0c_e + (long long)2 * t * se.PSb : nullptr,
                           lite ? P.Pb_e + (long long)2 * t * PbS_e : nullptr, t > 0,
-                          lite && t + 1 < Ti ? P.x0b_e + (long long)2 * (t + 1) * se.PSb : nullptr,
+                          (lite || P.x3r) && t + 1 < Ti ? P.x0b_e + (long long)2 * (t + 1) * se.PSb : nullptr,
                           P.Xp_e ? P.Xp_e + (long long)t * P.nb * R * 4 : nullptr));
     // ---- memory head (:159-166, :178-179): writes decoder state [h_t | value] into Zdec[0]
     CKI(memory_fwd_launch(P.Zenc + Ti * se.ZT, se.Cp, p->Wq, p->Memory, B, N, H, M, D, P.q_rows, P.att_rows,
@@ -2087,7 +2094,7 @@ static int model_forward(const mcrn_dims_t* d, const mcrn_params_t* p, const flo
                           P.hc_d + t * R * Hd, wd, Zn, sd.Cp, st, P.bf16 ? P.x0b_d + (long long)2 * t * sd.PSb : nullptr,
                           P.bf16 ? P.x0c_d + (long long)2 * t * sd.PSb : nullptr,
                           lite ? P.Pb_d + (long long)2 * t * PbS_d : nullptr, t > 0,
-                          lite && t + 1 < To ? P.x0b_d + (long long)2 * (t + 1) * sd.PSb : nullptr,
+                          (lite || P.x3r) && t + 1 < To ? P.x0b_d + (long long)2 * (t + 1) * sd.PSb : nullptr,
                           P.Xp_d ? P.Xp_d + (long long)t * P.nb * R * 4 : nullptr));
         const bool last = t + 1 == To;
         const float* lab = (teacher && teacher[t] && labels) ? labels + (long long)t * N * od : nullptr;

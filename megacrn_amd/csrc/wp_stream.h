@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void wp_stream_kernel(const WpP p) {
                     if (isz) {
                         const float zh = g * hv[v];
                         p.out2[r * p.out2_ld + c] = zh;
-                        if (p.out2b) p.out2b[r * H + c] = bf16_rne(zh);
+                        if (p.out2b) {
+                            const unsigned short hb = bf16_rne(zh);
+                            p.out2b[r * H + c] = hb;
+                            if (p.out2b_lo > 0) p.out2b[p.out2b_lo + r * H + c] = bf16_rne(zh - __uint_as_float((unsigned)hb << 16));
+                        }
                     }
                 }
             }
@@ -278,7 +282,11 @@ __global__ __launch_bounds__(256) void wp_stream_kernel(const WpP p) {
                     p.out[r * H + c] = hc;
                     const float hn = rg[v] * hv[v] + (1.f - rg[v]) * hc;
                     p.out2[r * p.out2_ld + c] = hn;
-                    if (p.out2b) p.out2b[r * H + c] = bf16_rne(hn);
+                    if (p.out2b) {
+                        const unsigned short hb = bf16_rne(hn);
+                        p.out2b[r * H + c] = hb;
+                        if (p.out2b_lo > 0) p.out2b[p.out2b_lo + r * H + c] = bf16_rne(hn - __uint_as_float((unsigned)hb << 16));
+                    }
                 }
             }
         }

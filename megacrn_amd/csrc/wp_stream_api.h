@@ -26,6 +26,7 @@ struct WpP {
     float* out2;              // GATE: z*h (columns < H), UPDATE: h' = r*h + (1-r)*hc ; row stride out2_ld
     long long out2_ld;
     uint16_t* out2b;          // nullable: the same values as packed bf16 [R][H] = the [N][B*H] operand of the next propagation GEMM
+    long long out2b_lo;       // > 0 (a bf16x3 session on the resident data flow, x3r): the rounding residuals as a second bf16 image that many elements behind
     const float* hsrc;        // UPDATE: previous state h[r*hsrc_ld + c]   (GATE reads it from plane 0 of Z)
     long long hsrc_ld;
     const float* zr;          // UPDATE: the gate call's `out`
